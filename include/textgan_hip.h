@@ -1,0 +1,163 @@
+/*
+ * textgan_hip.h -- C ABI of libtextgan_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the Monte-Carlo rollout reward path of
+ * williamSYSU/TextGAN-PyTorch.  The reference has no FFI of its own (it is
+ * pure Python on ATen), so every entry point below names the reference Python
+ * symbol (file:line under the reference tree) whose arithmetic it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - all floating-point data is fp32, all token ids are int64 (the
+ *     reference's dtypes: utils/rollout.py:41, models/generator.py:68);
+ *   - row-major, innermost index last;
+ *   - every call enqueues work on `stream` and returns without synchronising;
+ *     inputs are borrowed, outputs are caller-allocated;
+ *   - return value: 0 = ok, <0 = error (message via tg_last_error()).
+ *   - no entry point allocates device memory: scratch comes in through the
+ *     `workspace` arguments, sized by the *_workspace_bytes() helpers.
+ */
+#ifndef TEXTGAN_HIP_H
+#define TEXTGAN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TG_MAX_FILTERS 16
+
+#define TG_OK 0
+#define TG_ERR_ARG (-1)      /* bad argument / unsupported shape            */
+#define TG_ERR_LAUNCH (-2)   /* HIP launch or runtime error                 */
+#define TG_ERR_WORKSPACE (-3)/* workspace too small                         */
+
+/* LSTMGenerator parameters: models/generator.py:33-35 (state_dict keys
+ * embeddings.weight, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0,
+ * lstm.bias_hh_l0, lstm2out.weight, lstm2out.bias).  Gate order i,f,g,o. */
+typedef struct TgGenWeights {
+    const float* emb;    /* [V, E]   */
+    const float* w_ih;   /* [4H, E]  */
+    const float* w_hh;   /* [4H, H]  */
+    const float* b_ih;   /* [4H]     */
+    const float* b_hh;   /* [4H]     */
+    const float* w_out;  /* [V, H]   */
+    const float* b_out;  /* [V]      */
+    int32_t V, E, H;
+    int32_t _pad;
+} TgGenWeights;
+
+/* CNNDiscriminator parameters: models/discriminator.py:30-36 (state_dict keys
+ * embeddings.weight, convs.k.weight [n_k,1,f_k,Ed], convs.k.bias,
+ * highway.weight/bias [F,F], feature2out.weight/bias [n_out,F]). */
+typedef struct TgDisWeights {
+    const float* emb;                     /* [V, Ed]                 */
+    const float* conv_w[TG_MAX_FILTERS];  /* [n_k, f_k*Ed]           */
+    const float* conv_b[TG_MAX_FILTERS];  /* [n_k]                   */
+    const float* hw_w;                    /* [F, F]                  */
+    const float* hw_b;                    /* [F]                     */
+    const float* out_w;                   /* [n_out, F]              */
+    const float* out_b;                   /* [n_out]                 */
+    int32_t f[TG_MAX_FILTERS];            /* filter widths f_k       */
+    int32_t n[TG_MAX_FILTERS];            /* filters per width n_k   */
+    int32_t n_filters;                    /* number of widths        */
+    int32_t V, Ed, F, n_out;
+    int32_t _pad;
+} TgDisWeights;
+
+/* Library / build identification ("textgan_hip <ver> gfx950"). host string. */
+const char* tg_version(void);
+
+/* Last error message of the calling thread. host string. */
+const char* tg_last_error(void);
+
+/* 0 if the (V,E,H) generator shape is supported by the compiled kernels. */
+int tg_gen_supported(int V, int E, int H);
+
+/* ---------------------------------------------------------------------------
+ * Teacher-forced generator pass.
+ * Replaces LSTMGenerator.forward (models/generator.py:40-60) over a whole
+ * [N,L] input with zero initial state (init_hidden, :102-109), as used by
+ * NLL.cal_nll (metrics/nll.py:59-61) and by the rollout prefix
+ * (utils/rollout.py:35-38).
+ *   inp        [N,L]      int64, token fed at each step
+ *   target     [N,L]      int64 or NULL; if given, logp_out[n,t] =
+ *                         log_softmax(logits[n,t,:])[target[n,t]]
+ *   logp_out   [N,L]      or NULL
+ *   lse_out    [N,L]      or NULL: log-sum-exp of logits[n,t,:]
+ *   logits_out [N,L,V]    or NULL: raw lstm2out outputs (parity tests only)
+ *   states_out [L+1,N,2,H] or NULL: (h,c) after 0..L consumed tokens
+ *                         (slot 0 = zeros); the rollout prefix states.
+ * If target, lse_out and logits_out are all NULL the vocab projection is
+ * skipped entirely (prefix-state mode). */
+int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
+                          const int64_t* target, int N, int L,
+                          float* logp_out, float* lse_out, float* logits_out,
+                          float* states_out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Monte-Carlo completions.
+ * Replaces ROLLOUT.rollout_mc_search (utils/rollout.py:25-55) for every
+ * (i, given_num) pair of ROLLOUT.get_reward's double loop (:143-145) in one
+ * launch, sharing the prefix LSTM state between all completions of a sentence.
+ *   sentences   [B,L]        int64
+ *   uniforms    [R,L,L,B]    fp32 in [0,1): the draw for rollout i,
+ *                            given_num g (1-based), position t, sentence b is
+ *                            uniforms[((i*L + g-1)*L + t)*B + b] (t >= g used)
+ *   completions [R,L,B,L]    int64: completions[i, g-1] is the [B,L] tensor
+ *                            rollout_mc_search(sentences, g) returns; g = L is
+ *                            the sentence itself.  Only i in [i_lo,i_hi) and
+ *                            g in [g_lo,g_hi] are written.
+ *   workspace   prefix states, tg_gen_rollout_workspace_bytes(B,L,H) bytes.
+ * Sampling is inverse-CDF in the canonical order documented in DESIGN.md
+ * ("canonical sampler") -- it replaces torch.multinomial(exp(out),1)
+ * (utils/rollout.py:49). */
+size_t tg_gen_rollout_workspace_bytes(int B, int L, int H);
+int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B,
+                   int L, int R, int g_lo, int g_hi, int i_lo, int i_hi,
+                   const float* uniforms, int64_t* completions,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Free-running sampling.
+ * Replaces the step loop of LSTMGenerator.sample (models/generator.py:71-81)
+ * for N rows at once: zero state, first input `start_letter`.
+ *   uniforms [L,N] fp32: draw for row n at position t is uniforms[t*N + n]
+ *   out      [N,L] int64 */
+int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
+                  const float* uniforms, int64_t* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * CNN discriminator scorer.
+ * Replaces CNNDiscriminator.forward / get_feature
+ * (models/discriminator.py:40-64) followed by F.softmax(...)[:, col]
+ * (utils/rollout.py:146-148).
+ *   seqs             [N,L]      int64
+ *   col                         softmax column (current_k + 1)
+ *   dropout_p                   0 = eval mode (identity)
+ *   dropout_uniforms [N,F]      or NULL; keep = u < 1-p, scale 1/(1-p)
+ *                               (nn.Dropout, discriminator.py:36,47)
+ *   reward_out       [N]        or NULL
+ *   logits_out       [N,n_out]  or NULL (feature2out outputs, parity tests)
+ *   feature_out      [N,F]      or NULL (get_feature output, parity tests)
+ *   workspace        tg_dis_workspace_bytes(w,N,L) bytes. */
+size_t tg_dis_workspace_bytes(const TgDisWeights* w, int N, int L);
+int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L,
+                 int col, float dropout_p, const float* dropout_uniforms,
+                 float* reward_out, float* logits_out, float* feature_out,
+                 void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Reward reshape + mean.
+ * Replaces torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153):
+ * a reinterpretation of the flat [R*L, B] buffer, not a permute:
+ *   out[b,t] = mean_{r<R} raw_flat[(b*L + t)*R + r]. */
+int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
+                     void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TEXTGAN_HIP_H */

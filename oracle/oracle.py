@@ -1,0 +1,200 @@
+"""ctypes front end of the CPU oracle (oracle/textgan_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- see the header of textgan_oracle.c.  Only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg import this module.
+Inputs are numpy state_dicts (the reference's parameter names) and numpy
+arrays; outputs are numpy arrays.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libtextgan_oracle.so")
+MAX_FILTERS = 16
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "textgan_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libtextgan_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return _SO
+
+
+class GenW(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")] + \
+               [("V", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("_pad", C.c_int32)]
+
+
+class DisW(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("conv_w", C.c_void_p * MAX_FILTERS), ("conv_b", C.c_void_p * MAX_FILTERS),
+                ("hw_w", C.c_void_p), ("hw_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+                ("f", C.c_int32 * MAX_FILTERS), ("n", C.c_int32 * MAX_FILTERS), ("n_filters", C.c_int32),
+                ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("_pad", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = C.CDLL(_SO)
+        _lib.orc_span_len.restype = C.c_int
+        _lib.orc_group_tiles.restype = C.c_int
+        _lib.orc_num_threads.restype = C.c_int
+        _lib.orc_dis_forward.restype = C.c_int
+        _lib.orc_get_reward.restype = C.c_int
+    return _lib
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Gen:
+    """Holds fp32 copies of an LSTMGenerator state_dict (models/generator.py:33-35)."""
+
+    def __init__(self, sd):
+        g = lambda k: _f32(np.asarray(sd[k]))
+        self.a = [g("embeddings.weight"), g("lstm.weight_ih_l0"), g("lstm.weight_hh_l0"), g("lstm.bias_ih_l0"),
+                  g("lstm.bias_hh_l0"), g("lstm2out.weight"), g("lstm2out.bias")]
+        self.V, self.E = self.a[0].shape
+        self.H = self.a[2].shape[1]
+        self.w = GenW(*[x.ctypes.data for x in self.a], self.V, self.E, self.H, 0)
+
+
+class Dis:
+    """Holds fp32 copies of a CNNDiscriminator state_dict (models/discriminator.py:30-36)."""
+
+    def __init__(self, sd):
+        g = lambda k: _f32(np.asarray(sd[k]))
+        self.keep = []
+        w = DisW()
+        emb = g("embeddings.weight"); self.keep.append(emb)
+        w.emb = emb.ctypes.data
+        self.V, self.Ed = emb.shape
+        k = 0
+        F = 0
+        while "convs.%d.weight" % k in sd:
+            cw = g("convs.%d.weight" % k); cb = g("convs.%d.bias" % k)
+            n, _, f, ed = cw.shape
+            cw = np.ascontiguousarray(cw.reshape(n, f * ed))
+            self.keep += [cw, cb]
+            w.conv_w[k] = cw.ctypes.data; w.conv_b[k] = cb.ctypes.data
+            w.f[k] = f; w.n[k] = n
+            F += n; k += 1
+        w.n_filters = k
+        for name, key in (("hw_w", "highway.weight"), ("hw_b", "highway.bias"),
+                          ("out_w", "feature2out.weight"), ("out_b", "feature2out.bias")):
+            arr = g(key); self.keep.append(arr); setattr(w, name, arr.ctypes.data)
+        self.F = F
+        self.n_out = self.keep[-1].shape[0]
+        w.V, w.Ed, w.F, w.n_out = self.V, self.Ed, F, self.n_out
+        self.w = w
+
+
+def num_threads():
+    return lib().orc_num_threads()
+
+
+def span_len(V):
+    return lib().orc_span_len(int(V))
+
+
+def group_tiles(V):
+    return lib().orc_group_tiles(int(V))
+
+
+def sample_from_probs(p, u):
+    """Canonical inverse-CDF draw; the golden harness's torch.multinomial(p,1)."""
+    p = _f32(p); u = _f32(u)
+    N, V = p.shape
+    tok = np.empty(N, np.int64)
+    lib().orc_sample_from_probs(_p(p), _p(u), N, V, _p(tok))
+    return tok
+
+
+def gen_teacher_forced(gen, inp, target=None, want_logits=False, want_states=False):
+    inp = _i64(inp)
+    N, L = inp.shape
+    tgt = None if target is None else _i64(target)
+    logp = np.empty((N, L), np.float32) if tgt is not None else None
+    lse = np.empty((N, L), np.float32)
+    logits = np.empty((N, L, gen.V), np.float32) if want_logits else None
+    states = np.empty((L + 1, N, 2, gen.H), np.float32) if want_states else None
+    lib().orc_gen_teacher_forced(C.byref(gen.w), _p(inp), _p(tgt), N, L, _p(logp), _p(lse), _p(logits), _p(states))
+    return {"logp": logp, "lse": lse, "logits": logits, "states": states}
+
+
+def gen_rollout(gen, sentences, R, uniforms, i_lo=0, i_hi=None, forced=None):
+    s = _i64(sentences)
+    B, L = s.shape
+    i_hi = R if i_hi is None else i_hi
+    u = _f32(uniforms)
+    assert u.size == R * L * L * B
+    comp = np.zeros((R, L, B, L), np.int64)
+    f = None if forced is None else _i64(forced)
+    lib().orc_gen_rollout(C.byref(gen.w), _p(s), B, L, R, i_lo, i_hi, _p(u), _p(f), _p(comp))
+    return comp
+
+
+def gen_sample(gen, N, L, start_letter, uniforms, forced=None):
+    u = _f32(uniforms)
+    assert u.size == L * N
+    out = np.empty((N, L), np.int64)
+    f = None if forced is None else _i64(forced)
+    lib().orc_gen_sample(C.byref(gen.w), N, L, C.c_int64(start_letter), _p(u), _p(f), _p(out))
+    return out
+
+
+def dis_forward(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_feature=False):
+    s = _i64(seqs)
+    N, L = s.shape
+    du = None if dropout_uniforms is None else _f32(dropout_uniforms)
+    reward = np.empty(N, np.float32)
+    logits = np.empty((N, dis.n_out), np.float32)
+    feat = np.empty((N, dis.F), np.float32) if want_feature else None
+    rc = lib().orc_dis_forward(C.byref(dis.w), _p(s), N, L, col, C.c_float(dropout_p), _p(du),
+                               _p(reward), _p(logits), _p(feat))
+    if rc:
+        raise RuntimeError("oracle: sequence length %d shorter than a filter width" % L)
+    return {"reward": reward, "logits": logits, "feature": feat}
+
+
+def reward_reduce(raw, B, L, R):
+    raw = _f32(raw)
+    out = np.empty((B, L), np.float32)
+    lib().orc_reward_reduce(_p(raw), B, L, R, _p(out))
+    return out
+
+
+def get_reward(gen, dis, sentences, R, uniforms, col=1, dropout_p=0.0, dropout_uniforms=None,
+               i_lo=0, i_hi=None, reduce=True):
+    """ROLLOUT.get_reward (utils/rollout.py:128-154). Returns dict(completions, raw, reward)."""
+    s = _i64(sentences)
+    B, L = s.shape
+    i_hi = R if i_hi is None else i_hi
+    u = _f32(uniforms)
+    du = None if dropout_uniforms is None else _f32(dropout_uniforms)
+    comp = np.zeros((R, L, B, L), np.int64)
+    raw = np.zeros((R * L, B), np.float32)
+    out = np.empty((B, L), np.float32) if reduce else None
+    rc = lib().orc_get_reward(C.byref(gen.w), C.byref(dis.w), _p(s), B, L, R, i_lo, i_hi, col, _p(u),
+                              C.c_float(dropout_p), _p(du), _p(comp), _p(raw), _p(out))
+    if rc:
+        raise RuntimeError("oracle: sequence length %d shorter than a filter width" % L)
+    return {"completions": comp, "raw": raw, "reward": out}

@@ -1,0 +1,80 @@
+"""Rebuild golden-case inputs from the seeds stored in tests/golden/*.npz."""
+import glob
+import os
+
+import numpy as np
+
+import textgan_pytorch_amd as tg
+
+synth = tg.synth
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False)
+    return {k: (z[k].item() if z[k].ndim == 0 else z[k]) for k in z.files}
+
+
+def names(kind):
+    out = []
+    for p in sorted(glob.glob(os.path.join(GOLDEN, "*.npz"))):
+        z = np.load(p, allow_pickle=False)
+        if str(z["kind"]) == kind:
+            out.append(os.path.basename(p)[:-4])
+    return out
+
+
+def gen_sd(c):
+    return synth.gen_state(int(c["V"]), int(c["E"]), int(c["H"]), seed=int(c["gseed"]), std=float(c["gstd"]))
+
+
+def dis_sd(c):
+    if str(c["dis_kind"]) == "seqgan":
+        return synth.dis_state(int(c["V"]), 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=int(c["dseed"]))
+    return synth.dis_state(int(c["V"]), 64, *synth.SENTIGAN_D_FILTERS, n_out=int(c["k_label"]) + 1,
+                           seed=int(c["dseed"]))
+
+
+def reward_inputs(c):
+    V, L, B, R = int(c["V"]), int(c["L"]), int(c["B"]), int(c["R"])
+    sent = synth.tokens(int(c["sseed"]), (B, L), V)
+    u = synth.uniform01(int(c["useed"]), (R, L, L, B))
+    du = None
+    if int(c["dropout"]):
+        F = sum(synth.SEQGAN_D_FILTERS[1] if str(c["dis_kind"]) == "seqgan" else synth.SENTIGAN_D_FILTERS[1])
+        du = synth.uniform01(int(c["useed"]) + 7, (R * L, B, F))
+    return sent, u, du
+
+
+def sampled_mask(R, L, B):
+    """True where completions[i, g-1, b, t] is a sampled position (t >= g)."""
+    g = np.arange(1, L + 1)[:, None]
+    t = np.arange(L)[None, :]
+    return np.broadcast_to((t >= g)[None, :, None, :], (R, L, B, L))
+
+
+def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, tie_tol=2e-5, max_check=200):
+    """Step-wise (replay-mode) token parity, north_star's criterion: >= 99.9 % of
+    sampled positions identical, and every disagreement a CDF tie within fp32
+    epsilon.  got_replay / ref: [R,L,B,L] completions, got_replay produced with
+    forced=ref; uniforms [R,L,L,B]."""
+    from oracle import oracle
+    R, L, B, _ = ref.shape
+    m = sampled_mask(R, L, B)
+    diff = (got_replay != ref) & m
+    agree = 1.0 - diff.sum() / max(1, m.sum())
+    assert agree >= min_agree, "step-wise token agreement %.6f" % agree
+    assert np.array_equal(got_replay[~m], ref[~m]), "prefix tokens must be copied verbatim"
+    idx = np.argwhere(diff)[:max_check]
+    for (i, gi, b, t) in idx:
+        row = ref[i, gi, b].astype(np.int64)
+        r = oracle.gen_teacher_forced(gen_oracle, row[None, :], want_logits=True)
+        lg = r["logits"][0, t - 1].astype(np.float64)
+        w = np.exp(lg - lg.max())
+        cdf = np.cumsum(w) / w.sum()
+        a, c = int(got_replay[i, gi, b, t]), int(ref[i, gi, b, t])
+        u = float(uniforms[i, gi, t, b])
+        lo, hi = min(a, c), max(a, c)
+        # every boundary between the two tokens must sit within tie_tol of u
+        assert np.all(np.abs(cdf[lo:hi] - u) <= tie_tol), (i, gi + 1, b, t, a, c, u, cdf[lo:hi])
+    return agree

@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REAL reference (build container only).
+
+Imports /root/reference (pure Python) with an empty ``nltk`` stub (nltk is not
+installed and never used on this path), loads build-generated weights
+(textgan-pytorch_amd/synth.py), and runs the reference's own
+``ROLLOUT.get_reward``, ``LSTMGenerator.forward/sample``, ``NLL.cal_nll`` and
+``CNNDiscriminator.forward`` on CPU.  Two substitutions, both by attribute patch
+(no reference file is modified or copied):
+
+  * ``torch.multinomial(p, 1)`` -> canonical inverse-CDF draw
+    (oracle.sample_from_probs) from a pre-drawn uniform tensor indexed
+    [i, given_num-1, t, b] (get_reward) or [t, n] (sample);
+  * optionally ``dis.dropout`` -> mask-from-uniform (keep = u < 1-p, scale
+    1/(1-p)) so the training-mode dropout of the reference is reproducible.
+
+The fixtures hold seeds/shapes of the inputs and the reference's OUTPUTS only.
+Nothing under tests/ or on the GPU box reads /root/reference.
+"""
+import os
+import sys
+import time
+import types
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+sys.modules.setdefault("nltk", types.ModuleType("nltk"))
+sys.path.insert(0, REF)
+sys.path.insert(0, ROOT)
+os.chdir("/tmp")
+
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+
+import config as cfg  # noqa: E402  (reference config.py)
+
+cfg.CUDA = False
+cfg.if_real_data = False
+cfg.data_shuffle = False
+cfg.gen_init = "normal"
+cfg.dis_init = "uniform"
+
+from metrics.nll import NLL  # noqa: E402
+from models.SeqGAN_D import SeqGAN_D  # noqa: E402
+from models.SeqGAN_G import SeqGAN_G  # noqa: E402
+from models.SentiGAN_D import SentiGAN_D  # noqa: E402
+from models.SentiGAN_G import SentiGAN_G  # noqa: E402
+from utils.data_loader import GenDataIter  # noqa: E402
+from utils.rollout import ROLLOUT  # noqa: E402
+
+import textgan_pytorch_amd as tg  # noqa: E402
+from oracle import oracle  # noqa: E402
+
+synth = tg.synth
+OUT = os.path.join(ROOT, "tests", "golden")
+_real_multinomial = torch.multinomial
+
+
+def to_torch_sd(sd):
+    return {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+
+
+def make_gen(V, E, H, L, seed, std, senti=False):
+    g = (SentiGAN_G if senti else SeqGAN_G)(E, H, V, L, 0, gpu=False)
+    g.load_state_dict(to_torch_sd(synth.gen_state(V, E, H, seed=seed, std=std)))
+    return g
+
+
+def make_dis(kind, V, seed, k_label=4):
+    if kind == "seqgan":
+        d = SeqGAN_D(64, V, 0, gpu=False)
+        sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=seed)
+    else:
+        d = SentiGAN_D(k_label, 64, V, 0, gpu=False)
+        sd = synth.dis_state(V, 64, *synth.SENTIGAN_D_FILTERS, n_out=k_label + 1, seed=seed)
+    d.load_state_dict(to_torch_sd(sd))
+    return d
+
+
+class UniformFeed:
+    """Replaces torch.multinomial: call c draws with the c-th slice of `order`."""
+
+    def __init__(self, slices):
+        self.slices = slices
+        self.c = 0
+
+    def __call__(self, p, num_samples, *a, **k):
+        assert num_samples == 1
+        u = self.slices[self.c]
+        self.c += 1
+        tok = oracle.sample_from_probs(p.detach().numpy(), u)
+        return torch.from_numpy(tok).view(-1, 1)
+
+
+class MaskDropout(nn.Module):
+    def __init__(self, p, uniforms):  # uniforms [calls, B, F]
+        super().__init__()
+        self.p, self.u, self.c = p, uniforms, 0
+
+    def forward(self, x):
+        u = torch.from_numpy(self.u[self.c])
+        self.c += 1
+        return torch.where(u < 1.0 - self.p, x * (1.0 / (1.0 - self.p)), torch.zeros_like(x))
+
+
+def run_get_reward(name, V, E, H, L, B, R, dis_kind, gseed, gstd, dseed, sseed, useed,
+                   current_k=0, dropout=False, senti=False, k_label=4):
+    t0 = time.time()
+    gen = make_gen(V, E, H, L, gseed, gstd, senti)
+    dis = make_dis(dis_kind, V, dseed, k_label)
+    sent = synth.tokens(sseed, (B, L), V)
+    u = synth.uniform01(useed, (R, L, L, B))
+    slices = [u[i, g - 1, t] for i in range(R) for g in range(1, L + 1) for t in range(g, L)]
+    p = float(dis.dropout.p)
+    du = None
+    if dropout:
+        F = dis.feature_dim
+        du = synth.uniform01(useed + 7, (R * L, B, F))
+        dis.dropout = MaskDropout(p, du)
+    else:
+        dis.eval()
+    # capture what rollout_mc_search returns and the raw reward rows
+    comps = []
+    orig = ROLLOUT.rollout_mc_search
+
+    def spy(self, sentences, given_num):
+        out = orig(self, sentences, given_num)
+        comps.append(out.numpy().copy())
+        return out
+
+    ROLLOUT.rollout_mc_search = spy
+    feed = UniformFeed(slices)
+    torch.multinomial = feed
+    try:
+        ro = ROLLOUT(gen, False)
+        rew = ro.get_reward(torch.from_numpy(sent), R, dis, current_k)
+    finally:
+        torch.multinomial = _real_multinomial
+        ROLLOUT.rollout_mc_search = orig
+    assert feed.c == len(slices) == R * B * 0 + R * L * (L - 1) // 2
+    comp = np.stack(comps).reshape(R, L, B, L)
+    # raw rows (before the view/mean scramble), recomputed by the reference D on the same completions
+    if dropout:
+        dis.dropout = MaskDropout(p, du)
+    with torch.no_grad():
+        raw = np.stack([torch.softmax(dis.forward(torch.from_numpy(comp[i, g])), -1)[:, current_k + 1].numpy()
+                        for i in range(R) for g in range(L)])
+    np.savez_compressed(
+        os.path.join(OUT, name + ".npz"),
+        kind="get_reward", V=V, E=E, H=H, L=L, B=B, R=R, dis_kind=dis_kind, gseed=gseed, gstd=gstd,
+        dseed=dseed, sseed=sseed, useed=useed, current_k=current_k, dropout=int(dropout),
+        dropout_p=p if dropout else 0.0, k_label=k_label,
+        completions=comp.astype(np.int32), raw=raw.astype(np.float32), reward=rew.numpy().astype(np.float32))
+    print("%s: %.1fs reward mean %.5f" % (name, time.time() - t0, float(rew.mean())))
+
+
+def run_forward_nll(name, V, E, H, L, N, batch, gseed, gstd, sseed, save_logits):
+    """LSTMGenerator.forward (teacher forced) + NLL.cal_nll through GenDataIter."""
+    t0 = time.time()
+    cfg.batch_size, cfg.max_seq_len, cfg.start_letter, cfg.vocab_size = batch, L, 1, V
+    gen = make_gen(V, E, H, L, gseed, gstd)
+    samples = synth.tokens(sseed, (N, L), V)
+    it = GenDataIter(torch.from_numpy(samples))
+    nll = NLL.cal_nll(gen, it.loader, nn.NLLLoss(), gpu=False)
+    inp, target = GenDataIter.prepare(torch.from_numpy(samples))
+    raw_logits = []
+    hook = gen.lstm2out.register_forward_hook(lambda m, i, o: raw_logits.append(o.detach().numpy().copy()))
+    with torch.no_grad():
+        nb = (N // batch) * batch
+        pred = gen.forward(inp[:nb], gen.init_hidden(nb))  # [(nb*L), V] log-probs
+    hook.remove()
+    logp_t = pred.gather(1, target[:nb].reshape(-1, 1)).view(nb, L).numpy()
+    per_batch = -logp_t.reshape(nb // batch, batch * L).mean(1)
+    out = dict(kind="forward_nll", V=V, E=E, H=H, L=L, N=N, batch=batch, gseed=gseed, gstd=gstd, sseed=sseed,
+               nll=float(nll), inp=inp.numpy().astype(np.int32), target=target.numpy().astype(np.int32),
+               logp_target=logp_t.astype(np.float32), per_batch_loss=per_batch.astype(np.float32))
+    if save_logits:
+        out["logits"] = raw_logits[0].reshape(nb, L, V)[:8].astype(np.float32)
+        out["logprobs"] = pred.numpy().reshape(nb, L, V)[:8].astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("%s: %.1fs nll %.4f" % (name, time.time() - t0, nll))
+
+
+def run_sample(name, V, E, H, L, num_samples, batch, gseed, gstd, useed, start_letter=1):
+    t0 = time.time()
+    gen = make_gen(V, E, H, L, gseed, gstd)
+    num_batch = num_samples // batch + 1 if num_samples != batch else 1  # generator.py:67
+    Ntot = num_batch * batch
+    u = synth.uniform01(useed, (L, Ntot))
+    slices = [u[t, bb * batch:(bb + 1) * batch] for bb in range(num_batch) for t in range(L)]
+    feed = UniformFeed(slices)
+    torch.multinomial = feed
+    try:
+        s = gen.sample(num_samples, batch, start_letter)
+    finally:
+        torch.multinomial = _real_multinomial
+    assert feed.c == len(slices)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="sample", V=V, E=E, H=H, L=L,
+                        num_samples=num_samples, batch=batch, gseed=gseed, gstd=gstd, useed=useed,
+                        start_letter=start_letter, samples=s.numpy().astype(np.int32))
+    print("%s: %.1fs" % (name, time.time() - t0))
+
+
+def run_dis(name, V, L, N, dis_kind, dseed, sseed, k_label=4):
+    """CNNDiscriminator.forward / get_feature in eval mode + L < max-filter error."""
+    dis = make_dis(dis_kind, V, dseed, k_label).eval()
+    seqs = synth.tokens(sseed, (N, L), V)
+    with torch.no_grad():
+        feat = dis.get_feature(torch.from_numpy(seqs)).numpy()
+        logits = dis.forward(torch.from_numpy(seqs)).numpy()
+    err = 0
+    try:
+        with torch.no_grad():
+            dis.forward(torch.from_numpy(seqs[:, :max(1, min(L, 3))]))
+    except RuntimeError:
+        err = 1
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), kind="dis", V=V, L=L, N=N, dis_kind=dis_kind, dseed=dseed,
+                        sseed=sseed, k_label=k_label, feature=feat.astype(np.float32),
+                        logits=logits.astype(np.float32), short_input_raises=err)
+    print("%s: done (short input raises=%d)" % (name, err))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    oracle.build()
+    torch.set_num_threads(8)
+    # get_reward: tiny peaked (oracle-style N(0,1) weights), tiny flat, SentiGAN k-way with live dropout,
+    # long sequences, and the C1 shape at reduced rollout_num
+    run_get_reward("reward_tiny_peaked", 200, 32, 32, 20, 8, 2, "seqgan", 11, 1.0, 12, 13, 14)
+    run_get_reward("reward_tiny_flat", 200, 32, 32, 20, 8, 3, "seqgan", 21, 0.2, 22, 23, 24)
+    run_get_reward("reward_tiny_dropout", 200, 32, 32, 20, 8, 2, "seqgan", 31, 0.3, 32, 33, 34, dropout=True)
+    run_get_reward("reward_senti_k2", 150, 32, 32, 20, 6, 2, "sentigan", 41, 0.3, 42, 43, 44,
+                   current_k=2, dropout=True, senti=True)
+    run_get_reward("reward_len51", 333, 32, 32, 51, 4, 2, "seqgan", 51, 0.25, 52, 53, 54)
+    run_get_reward("reward_c1_r2", 5000, 32, 32, 20, 64, 2, "seqgan", 0, 1.0, 0, 1, 2)
+    run_get_reward("reward_c2_r1", 5255, 32, 32, 51, 64, 1, "seqgan", 3, 1.0, 3, 4, 5)
+    run_get_reward("reward_c1_flat_r1", 5000, 32, 32, 20, 64, 1, "seqgan", 5, 0.1, 6, 7, 8)
+    # forward / NLL
+    run_forward_nll("nll_tiny", 200, 32, 32, 20, 43, 8, 61, 1.0, 62, save_logits=True)
+    run_forward_nll("nll_c5_slice", 5000, 32, 32, 20, 200, 64, 0, 1.0, 63, save_logits=False)
+    # sample
+    run_sample("sample_tiny", 200, 32, 32, 20, 20, 8, 71, 0.3, 72)
+    run_sample("sample_eq_batch", 5000, 32, 32, 20, 64, 64, 0, 1.0, 73)
+    # discriminator alone
+    run_dis("dis_seqgan", 300, 20, 16, "seqgan", 81, 82)
+    run_dis("dis_seqgan_len51", 300, 51, 6, "seqgan", 83, 84)
+    run_dis("dis_senti", 300, 20, 16, "sentigan", 85, 86)
+
+
+if __name__ == "__main__":
+    main()
