@@ -110,6 +110,10 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
  *                            rollout_mc_search(sentences, g) returns; g = L is
  *                            the sentence itself.  Only i in [i_lo,i_hi) and
  *                            g in [g_lo,g_hi] are written.
+ *   forced      [R,L,B,L]    int64 or NULL.  Replay mode for parity tests: the
+ *                            drawn token is still what is written, but the
+ *                            token fed to the next step is forced[...], so one
+ *                            fp32 CDF tie does not cascade down the row.
  *   workspace   prefix states, tg_gen_rollout_workspace_bytes(B,L,H) bytes.
  * Sampling is inverse-CDF in the canonical order documented in DESIGN.md
  * ("canonical sampler") -- it replaces torch.multinomial(exp(out),1)
@@ -117,17 +121,20 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
 size_t tg_gen_rollout_workspace_bytes(int B, int L, int H);
 int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B,
                    int L, int R, int g_lo, int g_hi, int i_lo, int i_hi,
-                   const float* uniforms, int64_t* completions,
-                   void* workspace, size_t workspace_bytes, void* stream);
+                   const float* uniforms, const int64_t* forced,
+                   int64_t* completions, void* workspace,
+                   size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Free-running sampling.
  * Replaces the step loop of LSTMGenerator.sample (models/generator.py:71-81)
  * for N rows at once: zero state, first input `start_letter`.
  *   uniforms [L,N] fp32: draw for row n at position t is uniforms[t*N + n]
+ *   forced   [N,L] int64 or NULL (replay mode, as in tg_gen_rollout)
  *   out      [N,L] int64 */
 int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
-                  const float* uniforms, int64_t* out, void* stream);
+                  const float* uniforms, const int64_t* forced, int64_t* out,
+                  void* stream);
 
 /* ---------------------------------------------------------------------------
  * CNN discriminator scorer.

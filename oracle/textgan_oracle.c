@@ -68,12 +68,12 @@ int orc_num_threads(void) {
 /* Canonical sampler geometry (shared definition with the HIP kernels,
  * DESIGN.md "canonical sampler"): the vocabulary is cut into ORC_NSPAN
  * contiguous spans of span_len = 16*ceil(V/128) entries; each span into groups
- * of group_tiles tiles of 16 entries, group_tiles = smallest power of two with
- * span_len/16/group_tiles <= 48. */
+ * of group_tiles tiles of 16 entries, group_tiles = smallest power of two (at
+ * most 8) with ceil(span_len/16/group_tiles) <= 16. */
 int orc_span_len(int V) { return ORC_TILE * ((V + ORC_NSPAN * ORC_TILE - 1) / (ORC_NSPAN * ORC_TILE)); }
 int orc_group_tiles(int V) {
     int nt = orc_span_len(V) / ORC_TILE, gk = 1;
-    while ((nt + gk - 1) / gk > 48) gk *= 2;
+    while ((nt + gk - 1) / gk > 16 && gk < 8) gk *= 2;
     return gk;
 }
 

@@ -1,0 +1,232 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors of the real
+reference and against the CPU oracle on the same seeded inputs.  Tolerances are the
+north_star's: teacher-forced logits / NLL 1e-5 relative (fp32), sampled tokens >= 99.9 %
+step-wise with disagreements only at fp32 CDF ties, rewards 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+import _cases
+import textgan_pytorch_amd as tg
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+synth = _cases.synth
+DEV = "cuda"
+
+
+def _gen(c):
+    g = tg.modules.LSTMGenerator(int(c["E"]), int(c["H"]), int(c["V"]), int(c["L"]))
+    return tg.modules.load_numpy_state(g, _cases.gen_sd(c), DEV)
+
+
+def _dis(c):
+    if str(c["dis_kind"]) == "seqgan":
+        d = tg.modules.SeqGAN_D(64, int(c["V"]))
+    else:
+        d = tg.modules.SentiGAN_D(int(c["k_label"]), 64, int(c["V"]))
+    return tg.modules.load_numpy_state(d, _cases.dis_sd(c), DEV)
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+# ------------------------------------------------------------------ generator, teacher forced
+@pytest.mark.parametrize("name", _cases.names("forward_nll"))
+def test_teacher_forced_logits_and_nll(name):
+    c = _cases.load(name)
+    gen = _gen(c)
+    batch, L = int(c["batch"]), int(c["L"])
+    nb = (int(c["N"]) // batch) * batch
+    inp, tgt = _t(c["inp"][:nb].astype(np.int64)), _t(c["target"][:nb].astype(np.int64))
+    want_logits = "logits" in c
+    r = tg.ops.gen_teacher_forced(gen, inp, tgt, want_lse=True, want_logits=want_logits, want_states=True)
+    logp = r["logp"].cpu().numpy()
+    np.testing.assert_allclose(logp, c["logp_target"], rtol=1e-5, atol=1e-5)
+    per_batch = -logp.reshape(nb // batch, batch * L).mean(1)
+    np.testing.assert_allclose(per_batch, c["per_batch_loss"], rtol=1e-5)
+    # oracle on the same inputs: logits, lse, states
+    og = oracle.Gen(_cases.gen_sd(c))
+    o = oracle.gen_teacher_forced(og, c["inp"][:nb], c["target"][:nb], want_logits=want_logits, want_states=True)
+    np.testing.assert_allclose(r["lse"].cpu().numpy(), o["lse"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["states"].cpu().numpy(), o["states"], rtol=1e-4, atol=5e-5)  # internal state; chaotic N(0,1) LSTMs amplify 1-ulp gate differences
+    if want_logits:
+        lg = r["logits"].cpu().numpy()
+        np.testing.assert_allclose(lg[:8], c["logits"], rtol=1e-5, atol=2e-5)
+        np.testing.assert_allclose(lg, o["logits"], rtol=1e-5, atol=2e-5)
+        lp = tg.generator.forward_logprobs(gen, inp).view(nb, L, -1).cpu().numpy()
+        np.testing.assert_allclose(lp[:8], c["logprobs"], rtol=1e-5, atol=2e-5)
+    # the drop-in NLL surface: a loader of dicts, and the loader-free form
+    loader = [{"input": inp[i:i + batch].cpu(), "target": tgt[i:i + batch].cpu()} for i in range(0, nb, batch)]
+    assert tg.nll.cal_nll(gen, loader) == pytest.approx(c["nll"], abs=1.01e-4)
+    val, _ = tg.nll.nll_of_samples(gen, tgt, batch, start_letter=1)
+    assert val == pytest.approx(c["nll"], abs=1.01e-4)
+
+
+def test_teacher_forced_ragged_rows():
+    # N not a multiple of the 32-row tile, N == 1, and prefix-state mode (no projection)
+    V, L = 777, 7
+    sd = synth.gen_state(V, 32, 32, seed=5, std=0.5)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), sd, DEV)
+    og = oracle.Gen(sd)
+    for N in (1, 33, 70):
+        inp = synth.tokens(N, (N, L), V)
+        tgt = synth.tokens(N + 100, (N, L), V)
+        r = tg.ops.gen_teacher_forced(gen, _t(inp), _t(tgt), want_lse=True, want_states=True)
+        o = oracle.gen_teacher_forced(og, inp, tgt, want_states=True)
+        np.testing.assert_allclose(r["logp"].cpu().numpy(), o["logp"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(r["states"].cpu().numpy(), o["states"], rtol=1e-4, atol=5e-5)  # internal state; chaotic N(0,1) LSTMs amplify 1-ulp gate differences
+        s_only = tg.ops.gen_teacher_forced(gen, _t(inp), want_logp=False, want_states=True)["states"]
+        assert torch.equal(s_only, r["states"])
+
+
+# ------------------------------------------------------------------ generator, sampling
+@pytest.mark.parametrize("name", _cases.names("get_reward"))
+def test_rollout_tokens(name):
+    c = _cases.load(name)
+    gen = _gen(c)
+    sent, u, _ = _cases.reward_inputs(c)
+    R = int(c["R"])
+    ref = c["completions"].astype(np.int64)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref)).cpu().numpy()
+    og = oracle.Gen(_cases.gen_sd(c))
+    _cases.check_token_parity(replay, ref, u, og)
+    # against the oracle's own replay as well (same forced tokens)
+    orep = oracle.gen_rollout(og, sent, R, u, forced=ref)
+    m = _cases.sampled_mask(*ref.shape[:3])
+    assert (replay[m] == orep[m]).mean() >= 0.999
+    # free running: whole rows identical for the vast majority (a tie cascades down its row)
+    free = tg.ops.gen_rollout(gen, _t(sent), R, _t(u)).cpu().numpy()
+    assert (free == ref).all(-1).mean() >= 0.98
+
+
+@pytest.mark.parametrize("name", _cases.names("sample"))
+def test_sample(name):
+    c = _cases.load(name)
+    gen = _gen(c)
+    ns, batch, L = int(c["num_samples"]), int(c["batch"]), int(c["L"])
+    num_batch = ns // batch + 1 if ns != batch else 1
+    N = num_batch * batch
+    u = synth.uniform01(int(c["useed"]), (L, N))
+    forced = np.zeros((N, L), np.int64)
+    forced[:ns] = c["samples"]
+    out = tg.ops.gen_sample(gen, N, L, int(c["start_letter"]), _t(u), forced=_t(forced)).cpu().numpy()[:ns]
+    assert (out == c["samples"]).mean() >= 0.999
+    s = tg.generator.sample(gen, ns, batch, int(c["start_letter"]), uniforms=_t(u))
+    assert s.device.type == "cpu" and s.dtype == torch.int64 and tuple(s.shape) == (ns, L)
+    assert (s.numpy() == c["samples"]).all(-1).mean() >= 0.98
+
+
+def test_rollout_subranges_and_mc_search():
+    c = _cases.load("reward_tiny_flat")
+    gen = _gen(c)
+    sent, u, _ = _cases.reward_inputs(c)
+    R, L, B = int(c["R"]), int(c["L"]), int(c["B"])
+    full = tg.ops.gen_rollout(gen, _t(sent), R, _t(u))
+    part = torch.full_like(full, -1)
+    tg.ops.gen_rollout(gen, _t(sent), R, _t(u), g_lo=3, g_hi=5, i_lo=1, i_hi=2, out=part)
+    assert torch.equal(part[1, 2:5], full[1, 2:5])
+    assert (part[0] == -1).all() and (part[1, :2] == -1).all() and (part[1, 5:] == -1).all()
+    ro = tg.ROLLOUT(gen)
+    one = ro.rollout_mc_search(_t(sent), 4, uniforms=_t(u[:1]))
+    assert torch.equal(one, full[0, 3])
+    assert torch.equal(full[:, L - 1], _t(sent).expand(R, B, L))  # given_num == L is the sentence itself
+
+
+# ------------------------------------------------------------------ discriminator
+@pytest.mark.parametrize("name", _cases.names("dis"))
+def test_discriminator(name):
+    c = _cases.load(name)
+    dis = _dis(c).eval()
+    seqs = synth.tokens(int(c["sseed"]), (int(c["N"]), int(c["L"])), int(c["V"]))
+    r = tg.ops.dis_score(dis, _t(seqs), want_logits=True, want_feature=True)
+    np.testing.assert_allclose(r["feature"].cpu().numpy(), c["feature"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), c["logits"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(tg.discriminator.forward(dis, _t(seqs)).cpu().numpy(), c["logits"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(tg.discriminator.get_feature(dis, _t(seqs)).cpu().numpy(), c["feature"], rtol=1e-4,
+                               atol=2e-6)
+    if max(conv.kernel_size[0] for conv in dis.convs) > 3:
+        with pytest.raises(RuntimeError):  # the reference raises from conv2d when L < filter width
+            tg.ops.dis_score(dis, _t(seqs[:, :3]))
+
+
+@pytest.mark.parametrize("N", [1, 5, 129, 300])
+def test_discriminator_ragged_and_dropout(N):
+    V, L = 97, 23
+    sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=9)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), sd, DEV)
+    od = oracle.Dis(sd)
+    seqs = synth.tokens(N, (N, L), V)
+    du = synth.uniform01(N + 1, (N, od.F))
+    o = oracle.dis_forward(od, seqs, col=1, dropout_p=0.25, dropout_uniforms=du, want_feature=True)
+    r = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=0.25, dropout_uniforms=_t(du), want_logits=True,
+                         want_feature=True)
+    np.testing.assert_allclose(r["feature"].cpu().numpy(), o["feature"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
+
+
+# ------------------------------------------------------------------ get_reward end to end
+@pytest.mark.parametrize("name", _cases.names("get_reward"))
+def test_get_reward(name):
+    c = _cases.load(name)
+    gen, dis = _gen(c), _dis(c)
+    sent, u, du = _cases.reward_inputs(c)
+    R, L, B = int(c["R"]), int(c["L"]), int(c["B"])
+    if int(c["dropout"]):
+        dis.train()
+    else:
+        dis.eval()
+    ro = tg.ROLLOUT(gen, True)
+    rew, raw, comp = ro.get_reward(_t(sent), R, dis, int(c["current_k"]), uniforms=_t(u),
+                                   dropout_uniforms=None if du is None else _t(du), return_parts=True)
+    assert rew.is_cuda and rew.dtype == torch.float32 and tuple(rew.shape) == (B, L)
+    comp, raw, rew = comp.cpu().numpy(), raw.cpu().numpy(), rew.cpu().numpy()
+    same = (comp == c["completions"]).all(-1).reshape(R * L, B)
+    assert same.mean() >= 0.98
+    np.testing.assert_allclose(raw[same], c["raw"][same], atol=1e-4, rtol=0)
+    if same.all():
+        np.testing.assert_allclose(rew, c["reward"], atol=1e-4, rtol=0)
+    # the scorer on the reference's own completions: every raw row within 1e-4, and the reduce
+    d = tg.ops.dis_score(dis, _t(c["completions"].astype(np.int64).reshape(R * L * B, L)), col=int(c["current_k"]) + 1,
+                         dropout_p=float(c["dropout_p"]),
+                         dropout_uniforms=None if du is None else _t(du.reshape(R * L * B, -1)))
+    np.testing.assert_allclose(d["reward"].cpu().numpy().reshape(R * L, B), c["raw"], atol=1e-4, rtol=0)
+    red = tg.ops.reward_reduce(_t(c["raw"]), B, L, R).cpu().numpy()
+    np.testing.assert_allclose(red, c["reward"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(red, c["raw"].reshape(B, L, R).mean(-1), atol=1e-6, rtol=0)
+
+
+def test_get_reward_c1_full_vs_oracle():
+    """BASELINE config 1 at full size (V5000 L20 E=H=32 B64 R16): 20 480 completions against the
+    oracle; step-wise token parity, and rewards on rows whose completions agree."""
+    V, L, B, R = 5000, 20, 64, 16
+    gsd = synth.gen_state(V, 32, 32, seed=0, std=1.0)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=0)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), dsd, DEV).eval()
+    sent = synth.tokens(1, (B, L), V)
+    u = synth.uniform01(2, (R, L, L, B))
+    og, od = oracle.Gen(gsd), oracle.Dis(dsd)
+    o = oracle.get_reward(og, od, sent, R, u)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"])).cpu().numpy()
+    _cases.check_token_parity(replay, o["completions"], u, og, max_check=50)
+    rew, raw, comp = tg.ROLLOUT(gen).get_reward(_t(sent), R, dis, uniforms=_t(u), return_parts=True)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
+    assert same.mean() >= 0.98
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    # size-independent properties: rewards are probabilities, the g = L rows do not depend on i
+    rw = raw.cpu().numpy().reshape(R, L, B)
+    assert np.all((rw >= 0) & (rw <= 1))
+    assert np.array_equal(rw[:, L - 1], np.broadcast_to(rw[0, L - 1], (R, B)))
+    assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
+
+
+def test_errors_and_cpu_inputs():
+    gen = tg.modules.synthetic_generator(100, 32, 32, 20, device=DEV)
+    with pytest.raises(RuntimeError):
+        tg.ROLLOUT(gen).get_reward(torch.zeros(4, 20, dtype=torch.long), 2, None)  # CPU tensor
+    bad = tg.modules.LSTMGenerator(48, 48, 100, 20).to(DEV)
+    with pytest.raises(RuntimeError):
+        tg.ops.gen_sample(bad, 4, 20, 1, torch.rand(20, 4, device=DEV))

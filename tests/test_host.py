@@ -1,0 +1,72 @@
+"""CPU-side checks: the C-ABI library loads and exports every declared symbol, host logic
+(shard plan, sample batching rule, synthetic generator determinism), error behaviour."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import textgan_pytorch_amd as tg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "textgan_hip.h")).read()
+    declared = set(re.findall(r"\b(tg_[a-z_0-9]+)\s*\(", hdr))
+    assert declared >= set(tg._lib.SYMBOLS)
+    lib = ctypes.CDLL(tg._lib.LIB_PATH)
+    for s in declared:
+        assert hasattr(lib, s), s
+    lib.tg_version.restype = ctypes.c_char_p
+    assert b"gfx950" in lib.tg_version()
+
+
+def test_struct_layouts_match_header():
+    # 7 pointers + 4 int32 / see TgDisWeights in include/textgan_hip.h
+    assert ctypes.sizeof(tg._lib.GenW) == 7 * 8 + 16
+    assert ctypes.sizeof(tg._lib.DisW) == 8 + 2 * 16 * 8 + 4 * 8 + 2 * 16 * 4 + 6 * 4
+
+
+def test_no_cpu_fallback():
+    gen = tg.modules.synthetic_generator(50, 32, 32, 20, device="cpu")
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        tg.ROLLOUT(gen).get_reward(torch.zeros(2, 20, dtype=torch.long), 2, None)
+    with pytest.raises(RuntimeError):
+        tg.ops.gen_sample(gen, 4, 20, 1, torch.rand(20, 4))
+
+
+def test_rollout_attributes_mirror_reference():
+    gen = tg.modules.synthetic_generator(50, 32, 32, 20, device="cpu")
+    ro = tg.ROLLOUT(gen, gpu=True)
+    assert (ro.gen is gen and ro.max_seq_len == 20 and ro.vocab_size == 50 and ro.step_size == 0
+            and ro.goal_out_size == 0 and ro.gpu is True)
+    assert ro.old_model is not gen and ro.old_model.vocab_size == 50  # lazy deep copy (rollout.py:18)
+
+
+def test_shard_plan():
+    P = tg.dist.ShardPlan
+    for R in (1, 7, 16, 64):
+        for W in (1, 2, 3, 4, 8):
+            plans = [P(R, W, r) for r in range(W)]
+            assert plans[0].i_lo == 0 and plans[-1].i_hi == R
+            assert all(a.i_hi == b.i_lo for a, b in zip(plans, plans[1:]))
+            assert max(p.i_hi - p.i_lo for p in plans) - min(p.i_hi - p.i_lo for p in plans) <= 1
+            assert plans[0].even == (R % W == 0)
+    with pytest.raises(ValueError):
+        P(4, 2, 2)
+
+
+def test_synth_is_deterministic_and_shaped():
+    a, b = tg.synth.gen_state(100, 32, 32, seed=3), tg.synth.gen_state(100, 32, 32, seed=3)
+    assert all(np.array_equal(a[k], b[k]) for k in a)
+    assert a["lstm.weight_ih_l0"].shape == (128, 32) and a["lstm2out.weight"].shape == (100, 32)
+    d = tg.synth.dis_state(100, 64, *tg.synth.SEQGAN_D_FILTERS)
+    assert d["convs.11.weight"].shape == (160, 1, 20, 64) and d["highway.weight"].shape == (1720, 1720)
+    assert float(np.abs(d["highway.weight"]).max()) <= 0.0500001
+    u = tg.synth.uniform01(1, (1000,))
+    assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1
+    g = tg.modules.synthetic_generator(100, 32, 32, 20, device="cpu")
+    assert sorted(g.state_dict()) == sorted(a)

@@ -1,0 +1,146 @@
+"""ctypes binding of libtextgan_hip.so (the C ABI in include/textgan_hip.h).
+
+There is no CPU fallback: if the library is missing or a tensor is not a CUDA
+(ROCm) tensor, every entry point raises RuntimeError.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtextgan_hip.so")
+MAX_FILTERS = 16
+MAX_OUT = 8
+
+SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
+           "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample", "tg_dis_workspace_bytes",
+           "tg_dis_score", "tg_reward_reduce"]
+
+
+class GenW(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")] + \
+               [("V", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("_pad", C.c_int32)]
+
+
+class DisW(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("conv_w", C.c_void_p * MAX_FILTERS), ("conv_b", C.c_void_p * MAX_FILTERS),
+                ("hw_w", C.c_void_p), ("hw_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
+                ("f", C.c_int32 * MAX_FILTERS), ("n", C.c_int32 * MAX_FILTERS), ("n_filters", C.c_int32),
+                ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("_pad", C.c_int32)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP library (once). Raises RuntimeError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("textgan HIP extension not built: %s is missing "
+                               "(run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C textgan-pytorch_amd/csrc`)" % LIB_PATH)
+        l = C.CDLL(LIB_PATH)
+        l.tg_version.restype = C.c_char_p
+        l.tg_last_error.restype = C.c_char_p
+        l.tg_gen_rollout_workspace_bytes.restype = C.c_size_t
+        l.tg_dis_workspace_bytes.restype = C.c_size_t
+        l.tg_dis_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.tg_gen_teacher_forced.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5
+        l.tg_gen_rollout.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_size_t,
+                                                                                                  C.c_void_p]
+        l.tg_gen_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p]
+        l.tg_dis_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5 + \
+                                  [C.c_size_t, C.c_void_p]
+        l.tg_reward_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        for fn in ("tg_gen_supported", "tg_gen_teacher_forced", "tg_gen_rollout", "tg_gen_sample", "tg_dis_score",
+                   "tg_reward_reduce"):
+            getattr(l, fn).restype = C.c_int
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("textgan_hip: %s (code %d)" % (lib().tg_last_error().decode(), rc))
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_ptr(t, dtype=None, name="tensor"):
+    """Device pointer of a contiguous CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("textgan_hip: %s must be a CUDA (ROCm) tensor, got device %s -- there is no CPU path"
+                           % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise RuntimeError("textgan_hip: %s must be %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise RuntimeError("textgan_hip: %s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _param(p, name):
+    d = p.detach()
+    if d.dtype != torch.float32 or not d.is_contiguous():
+        d = d.float().contiguous()
+    return d, dev_ptr(d, torch.float32, name)
+
+
+def gen_weights(gen):
+    """Pack the live parameters of an LSTMGenerator-shaped module (models/generator.py:33-35).
+    Read on every call: the generator is stepped between get_reward calls."""
+    keep = []
+    ptrs = []
+    for name, p in (("embeddings.weight", gen.embeddings.weight), ("lstm.weight_ih_l0", gen.lstm.weight_ih_l0),
+                    ("lstm.weight_hh_l0", gen.lstm.weight_hh_l0), ("lstm.bias_ih_l0", gen.lstm.bias_ih_l0),
+                    ("lstm.bias_hh_l0", gen.lstm.bias_hh_l0), ("lstm2out.weight", gen.lstm2out.weight),
+                    ("lstm2out.bias", gen.lstm2out.bias)):
+        d, ptr = _param(p, name)
+        keep.append(d)
+        ptrs.append(ptr)
+    V, E = keep[0].shape
+    H = keep[2].shape[1]
+    if keep[1].shape != (4 * H, E) or keep[5].shape != (V, H):
+        raise RuntimeError("textgan_hip: generator parameter shapes are inconsistent")
+    w = GenW(*ptrs, V, E, H, 0)
+    if lib().tg_gen_supported(V, E, H) != 0:
+        raise RuntimeError("textgan_hip: generator shape V=%d E=%d H=%d is not supported by the compiled kernels "
+                           "(E = H = 32)" % (V, E, H))
+    return w, keep
+
+
+def dis_weights(dis):
+    """Pack the live parameters of a CNNDiscriminator-shaped module (models/discriminator.py:30-36)."""
+    keep = []
+    w = DisW()
+    d, w.emb = _param(dis.embeddings.weight, "embeddings.weight")
+    keep.append(d)
+    V, Ed = d.shape
+    if len(dis.convs) > MAX_FILTERS:
+        raise RuntimeError("textgan_hip: more than %d filter widths" % MAX_FILTERS)
+    F = 0
+    for k, conv in enumerate(dis.convs):
+        cw, w.conv_w[k] = _param(conv.weight, "convs.%d.weight" % k)
+        cb, w.conv_b[k] = _param(conv.bias, "convs.%d.bias" % k)
+        keep += [cw, cb]
+        n, one, f, ed = cw.shape
+        if one != 1 or ed != Ed:
+            raise RuntimeError("textgan_hip: convs.%d.weight has shape %s, expected [n,1,f,%d]" % (k, tuple(cw.shape), Ed))
+        w.f[k], w.n[k] = f, n
+        F += n
+    w.n_filters = len(dis.convs)
+    d, w.hw_w = _param(dis.highway.weight, "highway.weight"); keep.append(d)
+    d, w.hw_b = _param(dis.highway.bias, "highway.bias"); keep.append(d)
+    d, w.out_w = _param(dis.feature2out.weight, "feature2out.weight"); keep.append(d)
+    n_out = d.shape[0]
+    d, w.out_b = _param(dis.feature2out.bias, "feature2out.bias"); keep.append(d)
+    if keep[-4].shape != (F, F) or keep[-2].shape != (n_out, F):
+        raise RuntimeError("textgan_hip: discriminator parameter shapes are inconsistent")
+    w.V, w.Ed, w.F, w.n_out = V, Ed, F, n_out
+    return w, keep

@@ -1,0 +1,498 @@
+// K-DIS: the CNN discriminator scorer (gfx950).
+//
+//   k_dis_conv     embedding gather -> LDS; all filter widths as implicit GEMMs on
+//                  v_mfma_f32_32x32x2_f32 (M = filters, N = (sequence, time), K = f*Ed);
+//                  bias + ReLU + max-over-time in registers; pooled [N,F] out.
+//   k_dis_highway  h = pooled . W_hw^T as a 128x128-tiled fp32 MFMA GEMM with the sequences
+//                  on the lanes, fused sigmoid/relu gate, dropout mask and the partial
+//                  feature2out dot; partial logits [N, chunks, n_out] out.
+//   k_dis_final    fixed-order sum of the partials + bias, softmax column -> reward.
+//
+// Replaces models/discriminator.py:40-64 and utils/rollout.py:146-148 of the reference.
+// Embedding dim Ed = 64 (config.py:113 of the reference) is compiled in.
+#include "tg_common.h"
+
+namespace {
+
+constexpr int kEd = 64;
+constexpr int kERow = 68;          // LDS floats per embedded token: 16-B aligned, slot = row index mod 16
+constexpr int kConvThreads = 512;  // 8 waves
+constexpr int kMaxItems = 192;
+constexpr int kMaxOut = 8;
+
+struct ConvItem {
+    uint8_t k;   // filter width index
+    uint8_t mt;  // 32-filter tile of that width
+};
+
+struct ConvArgs {
+    TgDisWeights w;
+    const int64_t* seqs;  // [N,L]
+    float* pooled;        // [N,F]
+    int N, L;
+    int S, log2S;         // sequences per workgroup (power of two <= 32), TT = 32 / S
+    int n_items;
+    int foff[TG_MAX_FILTERS];  // feature offset of each width
+    ConvItem items[kMaxItems]; // sorted by cost, heaviest first
+};
+
+__global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* ebuf = reinterpret_cast<float*>(smem);  // [L][S][68]
+    const int L = a.L, S = a.S, log2S = a.log2S, TT = 32 >> log2S;
+    int* ctr = reinterpret_cast<int*>(ebuf + (size_t)L * S * kERow);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int n = lane & 31;
+    const int hh = lane >> 5;
+    const int seq0 = blockIdx.x * S;
+
+    // ---- gather: token embeddings -> LDS, time-major [t][s][68]
+    for (int idx = tid; idx < L * S * (kEd / 4); idx += kConvThreads) {
+        const int c = idx & 15;           // 16-B chunk of the 256-B row
+        const int ts = idx >> 4;          // t*S + s
+        const int s = ts & (S - 1), t = ts >> log2S;
+        const int seq = tg_min(seq0 + s, a.N - 1);
+        int tok = (int)a.seqs[(size_t)seq * L + t];
+        tok = tg_min(tg_max(tok, 0), a.w.V - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tok * kEd + 4 * c);
+        *reinterpret_cast<f32x4*>(ebuf + (size_t)ts * kERow + 4 * c) = v;
+    }
+    if (tid == 0) *ctr = 0;
+    __syncthreads();
+
+    const int s = n & (S - 1);   // this lane's sequence within the workgroup
+    const int tsub = n >> log2S; // and its time sub-position within a tile
+
+    for (;;) {
+        int item = 0;
+        if (lane == 0) item = atomicAdd(ctr, 1);
+        item = __builtin_amdgcn_readfirstlane(item);
+        if (item >= a.n_items) break;
+        const int k = a.items[item].k, mt = a.items[item].mt;
+        const int f = a.w.f[k], nk = a.w.n[k];
+        const int K = f * kEd, T = L - f + 1;
+        const int arow = tg_min(mt * 32 + n, nk - 1);
+        const float* wp = a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
+        const int ntile = (T + TT - 1) >> (5 - log2S);  // ceil(T / TT)
+
+        float runmax[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) runmax[r] = TG_NEG_INF;
+
+        for (int nb0 = 0; nb0 < ntile; nb0 += 4) {
+            const int nbc = tg_min(4, ntile - nb0);
+            f32x16 acc[4];
+            int boff[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
+                const int t = tg_min((nb0 + nt) * TT + tsub, T - 1);
+                boff[nt] = (t * S + s) * kERow + 32 * hh;
+            }
+            for (int tau = 0; tau < f; ++tau) {
+                f32x4 av[8];
+                const f32x4* pa = reinterpret_cast<const f32x4*>(wp + tau * kEd);
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) av[jj] = pa[jj];
+                const int toff = tau * S * kERow;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        if (nt < nbc) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(ebuf + boff[nt] + toff + 4 * jj);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[nt] = TG_MFMA32(av[jj][e], bv[e], acc[nt]);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const bool ok = (nt < nbc) && ((nb0 + nt) * TT + tsub < T);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], ok ? acc[nt][r] : TG_NEG_INF);
+            }
+        }
+        // combine the TT time sub-positions of a sequence (lanes n, n+S, n+2S, ...)
+        for (int off = S; off < 32; off <<= 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], __shfl_xor(runmax[r], off, 64));
+        }
+        // bias + ReLU, store: D reg r -> filter mt*32 + (r&3) + 8*(r>>2) + 4*hh
+        if (tsub == 0 && seq0 + s < a.N) {
+            float* po = a.pooled + (size_t)(seq0 + s) * a.w.F + a.foff[k];
+            const float* pb = a.w.conv_b[k];
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int m0 = mt * 32 + 8 * rq + 4 * hh;
+                if (m0 + 4 <= nk && (((a.foff[k] + m0) | a.w.F) & 3) == 0) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
+                    *reinterpret_cast<f32x4*>(po + m0) = o;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (m0 + e < nk) po[m0 + e] = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+constexpr int kHwThreads = 256;
+constexpr int kHwTile = 128;   // 128 features x 128 sequences per workgroup
+constexpr int kHwBK = 32;
+constexpr int kHwStride = 36;  // LDS row stride (floats)
+
+struct HwArgs {
+    TgDisWeights w;
+    const float* pooled;       // [N,F]
+    const float* dropout_u;    // [N,F] or null
+    float* feature_out;        // [N,F] or null
+    float* partial;            // [N, nchunk, kMaxOut]
+    float keep, scale;         // keep = 1-p, scale = 1/(1-p); p == 0 -> keep = 2 (always), scale = 1
+    int N, nchunk, nseqtile;
+};
+
+__device__ __forceinline__ void hw_load_tile(float* dst, const float* src, int row0, int nrows, int k0, int F, int tid) {
+    // 128 rows x 32 floats; rows >= nrows are clamped, k >= F reads as 0
+    const bool vec = (F & 3) == 0;
+    for (int idx = tid; idx < kHwTile * (kHwBK / 4); idx += kHwThreads) {
+        const int r = idx >> 3, c = idx & 7;
+        const int row = tg_min(row0 + r, nrows - 1);
+        const int k = k0 + 4 * c;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        const float* p = src + (size_t)row * F + k;
+        if (vec) {
+            if (k < F) v = *reinterpret_cast<const f32x4*>(p);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (k + e < F) v[e] = p[e];
+        }
+        *reinterpret_cast<f32x4*>(dst + r * kHwStride + 4 * c) = v;
+    }
+}
+
+__global__ __launch_bounds__(kHwThreads) void k_dis_highway(const HwArgs a) {
+    __shared__ __attribute__((aligned(16))) float As[kHwTile * kHwStride];  // hw_w rows (output features)
+    __shared__ __attribute__((aligned(16))) float Bs[kHwTile * kHwStride];  // pooled rows (sequences)
+    __shared__ float red[2][kHwTile][kMaxOut];                              // cross-wave logit partials
+
+    const int F = a.w.F, n_out = a.w.n_out;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;  // wave tile: features wm*64.., sequences wn*64..
+    const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    // consecutive workgroups share the sequence tile (B operand) and walk the feature chunks
+    const int bn = blockIdx.x % a.nchunk, bm = blockIdx.x / a.nchunk;
+    const int f0 = bn * kHwTile, s0 = bm * kHwTile;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    for (int k0 = 0; k0 < F; k0 += kHwBK) {
+        __syncthreads();
+        hw_load_tile(As, a.w.hw_w, f0, F, k0, F, tid);
+        hw_load_tile(Bs, a.pooled, s0, a.N, k0, F, tid);
+        __syncthreads();
+        float af[2][16], bf[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float* pa = As + (wm * 64 + i * 32 + n) * kHwStride + 16 * hh;
+            const float* pb = Bs + (wn * 64 + i * 32 + n) * kHwStride + 16 * hh;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 va = *reinterpret_cast<const f32x4*>(pa + 4 * q);
+                const f32x4 vb = *reinterpret_cast<const f32x4*>(pb + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { af[i][4 * q + e] = va[e]; bf[i][4 * q + e] = vb[e]; }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = TG_MFMA32(af[i][j], bf[jn][j], acc[i][jn]);
+    }
+
+    // ---- epilogue: gate, dropout, partial feature2out dot (lane = sequence, regs = features)
+    float part[2][kMaxOut];
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) part[jn][o] = 0.f;
+    const bool vec = (F & 3) == 0;
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) {
+        const int seq = s0 + wn * 64 + jn * 32 + n;
+        const int seqc = tg_min(seq, a.N - 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int fb = f0 + wm * 64 + i * 32 + 8 * rq + 4 * hh;  // 4 consecutive features
+                if (fb >= F) continue;
+                float pv[4], uv[4];
+                const size_t o4 = (size_t)seqc * F + fb;
+                if (vec) {
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(a.pooled + o4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pv[e] = t[e];
+                    if (a.dropout_u) {
+                        const f32x4 u = *reinterpret_cast<const f32x4*>(a.dropout_u + o4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) uv[e] = u[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        pv[e] = (fb + e < F) ? a.pooled[o4 + e] : 0.f;
+                        uv[e] = (a.dropout_u && fb + e < F) ? a.dropout_u[o4 + e] : 0.f;
+                    }
+                }
+                float fv[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int fi = tg_min(fb + e, F - 1);
+                    const float h = acc[i][jn][4 * rq + e] + a.w.hw_b[fi];
+                    const float sg = tg_sigmoid(h);
+                    fv[e] = sg * __builtin_fmaxf(h, 0.f) + (1.f - sg) * pv[e];
+                }
+                if (a.feature_out && seq < a.N) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (fb + e < F) a.feature_out[o4 + e] = fv[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (fb + e >= F) continue;
+                    float d = fv[e];
+                    if (a.dropout_u) d = (uv[e] < a.keep) ? d * a.scale : 0.f;
+#pragma unroll
+                    for (int o = 0; o < kMaxOut; ++o)
+                        if (o < n_out) part[jn][o] = __builtin_fmaf(d, a.w.out_w[(size_t)o * F + fb + e], part[jn][o]);
+                }
+            }
+        }
+    }
+    // lanes n and n+32 hold the same sequence; then the two feature-half waves (wm = 0,1)
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) part[jn][o] += __shfl_xor(part[jn][o], 32, 64);
+    if (hh == 0) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) red[wm][wn * 64 + jn * 32 + n][o] = part[jn][o];
+    }
+    __syncthreads();
+    if (tid < kHwTile) {
+        const int seq = s0 + tid;
+        if (seq < a.N) {
+            float* po = a.partial + ((size_t)seq * a.nchunk + bn) * kMaxOut;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) po[o] = red[0][tid][o] + red[1][tid][o];
+        }
+    }
+}
+
+struct FinalArgs {
+    const float* partial;  // [N, nchunk, kMaxOut]
+    const float* out_b;
+    float* reward_out;     // [N] or null
+    float* logits_out;     // [N, n_out] or null
+    int N, nchunk, n_out, col;
+};
+
+__global__ __launch_bounds__(256) void k_dis_final(const FinalArgs a) {
+    const int seq = blockIdx.x * 256 + threadIdx.x;
+    if (seq >= a.N) return;
+    float lg[kMaxOut];
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) lg[o] = (o < a.n_out) ? a.out_b[o] : TG_NEG_INF;
+    const float* p = a.partial + (size_t)seq * a.nchunk * kMaxOut;
+    for (int c = 0; c < a.nchunk; ++c)
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o)
+            if (o < a.n_out) lg[o] += p[c * kMaxOut + o];
+    float M = TG_NEG_INF;
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) M = __builtin_fmaxf(M, lg[o]);
+    float S = 0.f, pick = 0.f;
+#pragma unroll
+    for (int o = 0; o < kMaxOut; ++o) {
+        const float e = tg_expf(lg[o] - M);
+        S += e;
+        pick = (o == a.col) ? e : pick;
+        if (a.logits_out && o < a.n_out) a.logits_out[(size_t)seq * a.n_out + o] = lg[o];
+    }
+    if (a.reward_out) a.reward_out[seq] = pick / S;
+}
+
+int check_dis(const TgDisWeights* w, int L) {
+    if (!w || !w->emb || !w->hw_w || !w->hw_b || !w->out_w || !w->out_b) {
+        tg_set_error("discriminator weights: null pointer");
+        return TG_ERR_ARG;
+    }
+    if (w->Ed != kEd) {
+        tg_set_error("discriminator embedding dim %d not supported by this build (64 only)", w->Ed);
+        return TG_ERR_ARG;
+    }
+    if (w->n_filters < 1 || w->n_filters > TG_MAX_FILTERS || w->n_out < 1 || w->n_out > kMaxOut) {
+        tg_set_error("discriminator: n_filters=%d n_out=%d out of range", w->n_filters, w->n_out);
+        return TG_ERR_ARG;
+    }
+    int F = 0;
+    for (int k = 0; k < w->n_filters; ++k) {
+        if (!w->conv_w[k] || !w->conv_b[k] || w->f[k] < 1 || w->n[k] < 1) {
+            tg_set_error("discriminator: bad filter bank %d", k);
+            return TG_ERR_ARG;
+        }
+        if (w->f[k] > L) {
+            // the reference raises RuntimeError from conv2d here (kernel larger than input)
+            tg_set_error("sequence length %d is shorter than filter width %d", L, w->f[k]);
+            return TG_ERR_ARG;
+        }
+        F += w->n[k];
+    }
+    if (F != w->F) {
+        tg_set_error("discriminator: feature dim %d != sum of filters %d", w->F, F);
+        return TG_ERR_ARG;
+    }
+    return TG_OK;
+}
+
+inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+extern "C" size_t tg_dis_workspace_bytes(const TgDisWeights* w, int N, int L) {
+    (void)L;
+    if (!w || N < 1) return 0;
+    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
+    return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut);
+}
+
+extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L, int col, float dropout_p,
+                            const float* dropout_uniforms, float* reward_out, float* logits_out, float* feature_out,
+                            void* workspace, size_t workspace_bytes, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N < 0 || L < 1 || !seqs) {
+        tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
+        return TG_ERR_ARG;
+    }
+    int rc = check_dis(w, L);
+    if (rc) return rc;
+    if (reward_out && (col < 0 || col >= w->n_out)) {
+        tg_set_error("tg_dis_score: softmax column %d outside [0,%d)", col, w->n_out);
+        return TG_ERR_ARG;
+    }
+    if (dropout_p < 0.f || dropout_p >= 1.f) {
+        tg_set_error("tg_dis_score: dropout p=%f outside [0,1)", dropout_p);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    if (!workspace || workspace_bytes < tg_dis_workspace_bytes(w, N, L)) {
+        tg_set_error("tg_dis_score: workspace too small (%zu < %zu)", workspace_bytes, tg_dis_workspace_bytes(w, N, L));
+        return TG_ERR_WORKSPACE;
+    }
+    float* pooled = (float*)workspace;
+    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
+    float* partial = (float*)((char*)workspace + align256(sizeof(float) * (size_t)N * w->F));
+
+    // ---- conv
+    ConvArgs ca = {};
+    ca.w = *w;
+    ca.seqs = seqs;
+    ca.pooled = pooled;
+    ca.N = N;
+    ca.L = L;
+    int S = 32, log2S = 5;
+    while (S > 1 && (size_t)L * S * kERow * sizeof(float) + 64 > 144 * 1024) { S >>= 1; --log2S; }
+    if ((size_t)L * S * kERow * sizeof(float) + 64 > 160 * 1024) {
+        tg_set_error("tg_dis_score: sequence length %d too long for the LDS-resident conv kernel", L);
+        return TG_ERR_ARG;
+    }
+    ca.S = S;
+    ca.log2S = log2S;
+    int off = 0, ni = 0;
+    struct Tmp { int k, mt; long cost; } tmp[kMaxItems];
+    for (int k = 0; k < w->n_filters; ++k) {
+        ca.foff[k] = off;
+        off += w->n[k];
+        for (int mt = 0; mt < (w->n[k] + 31) / 32; ++mt) {
+            if (ni >= kMaxItems) {
+                tg_set_error("tg_dis_score: too many filter tiles (> %d)", kMaxItems);
+                return TG_ERR_ARG;
+            }
+            tmp[ni].k = k; tmp[ni].mt = mt; tmp[ni].cost = (long)w->f[k] * (L - w->f[k] + 1);
+            ++ni;
+        }
+    }
+    for (int i = 1; i < ni; ++i) {  // insertion sort, heaviest first
+        Tmp t = tmp[i];
+        int j = i - 1;
+        while (j >= 0 && tmp[j].cost < t.cost) { tmp[j + 1] = tmp[j]; --j; }
+        tmp[j + 1] = t;
+    }
+    for (int i = 0; i < ni; ++i) { ca.items[i].k = (uint8_t)tmp[i].k; ca.items[i].mt = (uint8_t)tmp[i].mt; }
+    ca.n_items = ni;
+    const size_t sm = (size_t)L * S * kERow * sizeof(float) + 64;
+    static thread_local size_t conv_set = 0;
+    if (sm > 48 * 1024 && sm > conv_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_conv),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            tg_set_error("hipFuncSetAttribute(k_dis_conv): %s", hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        conv_set = sm;
+    }
+    hipLaunchKernelGGL(k_dis_conv, dim3((N + S - 1) / S), dim3(kConvThreads), sm, stream, ca);
+
+    // ---- highway + gate + dropout + partial logits
+    HwArgs ha = {};
+    ha.w = *w;
+    ha.pooled = pooled;
+    ha.dropout_u = (dropout_p > 0.f) ? dropout_uniforms : nullptr;
+    ha.feature_out = feature_out;
+    ha.partial = partial;
+    ha.keep = 1.f - dropout_p;
+    ha.scale = 1.f / (1.f - dropout_p);
+    ha.N = N;
+    ha.nchunk = nchunk;
+    ha.nseqtile = (N + kHwTile - 1) / kHwTile;
+    hipLaunchKernelGGL(k_dis_highway, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, ha);
+
+    // ---- final: fixed-order partial sum, softmax column
+    FinalArgs fa = {};
+    fa.partial = partial;
+    fa.out_b = w->out_b;
+    fa.reward_out = reward_out;
+    fa.logits_out = logits_out;
+    fa.N = N;
+    fa.nchunk = nchunk;
+    fa.n_out = w->n_out;
+    fa.col = col;
+    hipLaunchKernelGGL(k_dis_final, dim3((N + 255) / 256), dim3(256), 0, stream, fa);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        tg_set_error("tg_dis_score launch: %s", hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    return TG_OK;
+}

@@ -1,0 +1,591 @@
+// K-GEN: the LSTM generator as one persistent kernel per 32-row tile (gfx950).
+//
+// One workgroup (4 waves) owns 32 rows (completions / sequences) for ALL of their
+// timesteps: W_ih/W_hh live in VGPRs as MFMA A-operands, h lives in LDS (and in
+// VGPRs as the MFMA B-operand), c lives in VGPRs.  Per step:
+//   cell      gates[128 x 32rows] = [W_ih|W_hh] . [x;h]   32 x v_mfma_f32_32x32x2_f32 per wave
+//             (rows permuted so that each lane ends up with i,f,g,o of its own 4 units)
+//   project   logits[V x 32rows] = W_out . h + b          W_out streamed from L2, 16 MFMA per
+//             32x32 tile; the vocab is cut into 8 contiguous spans, one per (wave, lane-half),
+//             so every lane sees its span in natural vocab order, 16 entries per tile
+//   softmax   lane-local online max / sums per tile; per-group records (max, sum) in LDS
+//   sample    canonical inverse-CDF draw (fp64 above tile level) from a pre-drawn uniform,
+//             the chosen group's entries recomputed cooperatively; the token goes straight
+//             into the completions buffer and back into the next step's embedding gather.
+// Logits never touch HBM.  Replaces models/generator.py:40-84, utils/rollout.py:25-55 and
+// the forward inside metrics/nll.py:59-61 of the reference.
+//
+// This file implements E = H = 32 (SeqGAN / SentiGAN / MaliGAN / oracle configs).
+#include "tg_common.h"
+
+namespace {
+
+constexpr int kH = 32;        // hidden = embedding dim handled by this kernel
+constexpr int kRows = 32;     // rows per workgroup (MFMA N)
+constexpr int kThreads = 256; // 4 waves
+constexpr int kHStride = 36;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
+constexpr int kNSpan = 8;
+
+struct SamplerGeom {
+    int Ls;  // span length (entries)
+    int NT;  // tiles per span
+    int GK;  // tiles per group
+    int NG;  // groups per span
+};
+
+struct GenArgs {
+    TgGenWeights w;
+    SamplerGeom geo;
+    // ---- sampling modes (rollout / sample)
+    const int64_t* sentences;  // rollout: [B,L]
+    const float* states;       // rollout: [L+1,B,2,H] prefix states
+    const float* uniforms;
+    const int64_t* forced;     // nullable (replay mode)
+    int64_t* out;              // rollout: [R,L,B,L]; sample: [N,L]
+    int64_t start_letter;
+    int rollout;               // 1 = rollout tiles, 0 = free-running sample
+    int B, L, R, g_lo, i_lo;
+    int rows_g, tiles_g;       // rollout: rows and tiles per given_num
+    int N;                     // sample / teacher-forced rows
+    // ---- teacher-forced mode
+    const int64_t* inp;        // [N,L]
+    const int64_t* target;     // [N,L] or null
+    float* logp_out;           // [N,L] or null
+    float* lse_out;            // [N,L] or null
+    float* logits_out;         // [N,L,V] or null
+    float* states_out;         // [L+1,N,2,H] or null
+    int need_proj;
+};
+
+// One row of W_out (32 floats) dotted with h in the MFMA's own k order
+// (k pairs (j, 16+j), j = 0..15, starting from the bias), so that a recomputed
+// logit reproduces the MFMA result.
+__device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, const float* hrow, float bias) {
+    float acc = bias;
+    const f32x4* w4 = reinterpret_cast<const f32x4*>(wrow);
+    f32x4 wl[4], wh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { wl[i] = w4[i]; wh[i] = w4[4 + i]; }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        acc = __builtin_fmaf(wl[j >> 2][j & 3], hrow[j], acc);
+        acc = __builtin_fmaf(wh[j >> 2][j & 3], hrow[16 + j], acc);
+    }
+    return acc;
+}
+
+template <bool SAMPLE>
+__global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* hbuf = reinterpret_cast<float*>(smem);                 // [32][36]
+    float* mbuf = hbuf + kRows * kHStride;                         // [8][32]
+    double* sbuf = reinterpret_cast<double*>(mbuf + kNSpan * kRows);  // [8][32]
+    int* tokbuf = reinterpret_cast<int*>(sbuf + kNSpan * kRows);   // [32]
+    int* selv = tokbuf + kRows;                                    // [32] chosen group's first vocab id
+    float* Mbuf = reinterpret_cast<float*>(selv + kRows);          // [32] row max
+    double* selp = reinterpret_cast<double*>(Mbuf + kRows);        // [32] prefix before the group
+    double* tgt = selp + kRows;                                    // [32] target = u*S
+    float* wbuf = reinterpret_cast<float*>(tgt + kRows);           // [32][EG+1] recomputed weights
+    const int EG = a.geo.GK * 16;
+    float2* rec = reinterpret_cast<float2*>(wbuf + kRows * (EG + 1) + ((kRows * (EG + 1)) & 1));  // [NG][8][32]
+
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int n = lane & 31;
+    const int hh = lane >> 5;
+    const int sp = 2 * w + hh;
+    const int V = a.w.V, L = a.L;
+    const int Ls = a.geo.Ls, NT = a.geo.NT, GK = a.geo.GK;
+
+    // ------------------------------------------------------------------ row setup
+    bool valid;
+    int t0 = 0;
+    int tok;                       // pending input token of row n
+    const float* state0 = nullptr; // initial (h,c) of row n or null = zeros
+    int64_t* out_row = nullptr;
+    const int64_t* forced_row = nullptr;
+    const float* u_base = nullptr;
+    size_t u_stride = 0;
+    size_t tf_row = 0;             // teacher-forced: row index
+    if (SAMPLE) {
+        if (a.rollout) {
+            const int g = a.g_lo + blockIdx.x / a.tiles_g;
+            const int fr = (blockIdx.x % a.tiles_g) * kRows + n;
+            valid = fr < a.rows_g;
+            const int frc = valid ? fr : a.rows_g - 1;
+            const int i = a.i_lo + frc / a.B, b = frc % a.B;
+            const size_t row = ((size_t)i * L + (g - 1)) * a.B + b;
+            out_row = a.out + row * L;
+            forced_row = a.forced ? a.forced + row * L : nullptr;
+            u_base = a.uniforms + ((size_t)i * L + (g - 1)) * L * a.B + b;
+            u_stride = a.B;
+            t0 = g;
+            // prefix copy: the 8 (wave, half) threads of a row interleave over positions
+            if (valid)
+                for (int s = sp; s < g; s += kNSpan) out_row[s] = a.sentences[(size_t)b * L + s];
+            if (g >= L) return;  // given_num == L: the sentence itself (uniform per workgroup)
+            tok = (int)a.sentences[(size_t)b * L + g - 1];
+            state0 = a.states + ((size_t)(g - 1) * a.B + b) * 2 * kH;
+        } else {
+            const int fr = blockIdx.x * kRows + n;
+            valid = fr < a.N;
+            const int frc = valid ? fr : a.N - 1;
+            out_row = a.out + (size_t)frc * L;
+            forced_row = a.forced ? a.forced + (size_t)frc * L : nullptr;
+            u_base = a.uniforms + frc;
+            u_stride = a.N;
+            tok = (int)a.start_letter;
+        }
+    } else {
+        const int fr = blockIdx.x * kRows + n;
+        valid = fr < a.N;
+        tf_row = valid ? fr : a.N - 1;
+        tok = (int)a.inp[tf_row * L];
+        if (a.states_out && valid && w == 0) {  // slot 0 = zeros
+            float* s0 = a.states_out + tf_row * 2 * kH;
+            for (int k = hh * kH; k < hh * kH + kH; ++k) s0[k] = 0.f;
+        }
+    }
+
+    tok = tg_min(tg_max(tok, 0), V - 1);  // ids must be < V; clamped for memory safety
+
+    // ------------------------------------------------------------------ resident weights
+    // gate tile of wave w: tile row i -> gate i>>3, unit 8w + (i&7)
+    float wih[16], whh[16];
+    {
+        const int i = lane & 31;
+        const int grow = (i >> 3) * kH + 8 * w + (i & 7);
+        const f32x4* pi = reinterpret_cast<const f32x4*>(a.w.w_ih + (size_t)grow * kH + 16 * hh);
+        const f32x4* ph = reinterpret_cast<const f32x4*>(a.w.w_hh + (size_t)grow * kH + 16 * hh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 vi = pi[q], vh = ph[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { wih[4 * q + e] = vi[e]; whh[4 * q + e] = vh[e]; }
+        }
+    }
+    f32x16 gbias;  // D reg r: gate r>>2, unit 8w + 4hh + (r&3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int grow = (r >> 2) * kH + 8 * w + 4 * hh + (r & 3);
+        gbias[r] = a.w.b_ih[grow] + a.w.b_hh[grow];
+    }
+
+    // ------------------------------------------------------------------ initial state
+    const int ubase = 8 * w + 4 * hh;  // this lane's 4 hidden units
+    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
+    {
+        f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
+        if (state0) {
+            h4 = *reinterpret_cast<const f32x4*>(state0 + ubase);
+            c4 = *reinterpret_cast<const f32x4*>(state0 + kH + ubase);
+        }
+        *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ubase) = h4;
+    }
+    __syncthreads();
+    float hb[16];  // MFMA B operand: h[n][16hh + j]
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(hbuf + n * kHStride + 16 * hh + 4 * q);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) hb[4 * q + e] = v[e];
+    }
+    __syncthreads();  // everyone has read hbuf before the first cell overwrites it
+
+    // A-operand row of this lane in the projection tiles
+    const int am = lane & 31;
+    const int a_sp = 2 * w + ((am >> 2) & 1);
+    const int a_r = (am & 3) + 4 * (am >> 3);
+    const int last_span = (V - 1) / Ls;
+
+    for (int t = t0; t < L; ++t) {
+        // ============================================================== LSTM cell
+        {
+            float xb[16];
+            const f32x4* px = reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tok * kH + 16 * hh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = px[q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) xb[4 * q + e] = v[e];
+            }
+            f32x16 acc = gbias;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = TG_MFMA32(wih[j], xb[j], acc);
+#pragma unroll
+            for (int j = 0; j < 16; ++j) acc = TG_MFMA32(whh[j], hb[j], acc);
+            f32x4 h4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ig = tg_sigmoid(acc[e]);
+                const float fg = tg_sigmoid(acc[4 + e]);
+                const float gg = tg_tanh(acc[8 + e]);
+                const float og = tg_sigmoid(acc[12 + e]);
+                const float cn = fg * c4[e] + ig * gg;
+                c4[e] = cn;
+                h4[e] = og * tg_tanh(cn);
+            }
+            *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ubase) = h4;
+            if (!SAMPLE && a.states_out && valid) {
+                float* st = a.states_out + ((size_t)(t + 1) * a.N + tf_row) * 2 * kH;
+                *reinterpret_cast<f32x4*>(st + ubase) = h4;
+                *reinterpret_cast<f32x4*>(st + kH + ubase) = c4;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(hbuf + n * kHStride + 16 * hh + 4 * q);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) hb[4 * q + e] = v[e];
+        }
+        if (!SAMPLE && !a.need_proj) {
+            if (t + 1 < L) tok = tg_min(tg_max((int)a.inp[tf_row * L + t + 1], 0), V - 1);
+            __syncthreads();
+            continue;
+        }
+
+        // ============================================================== projection + online softmax
+        float m_run = TG_NEG_INF;
+        float c_grp = 0.f;   // SAMPLE: current group's sum at scale m_run; TF: running sum of the span
+        const int sp_lo = sp * Ls;
+        {
+            float a_cur[16], a_nxt[16] = {};
+            auto load_a = [&](int q, float (&dst)[16]) {
+                const int v = tg_min(a_sp * Ls + 16 * q + a_r, V - 1);
+                const f32x4* p = reinterpret_cast<const f32x4*>(a.w.w_out + (size_t)v * kH + 16 * hh);
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    const f32x4 vv = p[qq];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) dst[4 * qq + e] = vv[e];
+                }
+            };
+            load_a(0, a_cur);
+            for (int q = 0; q < NT; ++q) {
+                if (q + 1 < NT) load_a(q + 1, a_nxt);
+                const int vb = sp_lo + 16 * q;
+                f32x16 acc;
+                if (vb + 16 <= V) {
+                    const f32x4* pb = reinterpret_cast<const f32x4*>(a.w.b_out + vb);
+#pragma unroll
+                    for (int qq = 0; qq < 4; ++qq) {
+                        const f32x4 bv = pb[qq];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[4 * qq + e] = bv[e];
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[r] = a.w.b_out[tg_min(vb + r, V - 1)];
+                }
+#pragma unroll
+                for (int j = 0; j < 16; ++j) acc = TG_MFMA32(a_cur[j], hb[j], acc);
+                const int nvalid = tg_max(0, tg_min(16, V - vb));
+                if (!SAMPLE && a.logits_out && valid) {
+                    float* lo = a.logits_out + (tf_row * L + t) * (size_t)V + vb;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (r < nvalid) lo[r] = acc[r];
+                }
+                float tmax = TG_NEG_INF;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    acc[r] = (r < nvalid) ? acc[r] : TG_NEG_INF;
+                    tmax = __builtin_fmaxf(tmax, acc[r]);
+                }
+                const float m_new = __builtin_fmaxf(m_run, tmax);
+                const float m_safe = (m_new == TG_NEG_INF) ? 0.f : m_new;
+                const bool grp_start = SAMPLE && (q % GK == 0);
+                // rescale what was accumulated at the old max (exp(-inf) = 0 on the first tile)
+                c_grp = grp_start ? 0.f : c_grp * tg_expf(m_run - m_safe);
+                float ts = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ts += tg_expf(acc[r] - m_safe);
+                c_grp += ts;
+                m_run = m_new;
+                if (SAMPLE && ((q % GK == GK - 1) || q == NT - 1))
+                    rec[((q / GK) * kNSpan + sp) * kRows + n] = make_float2(m_run, c_grp);
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
+            }
+        }
+        mbuf[sp * kRows + n] = m_run;
+        __syncthreads();
+        float M = mbuf[n];
+#pragma unroll
+        for (int s = 1; s < kNSpan; ++s) M = __builtin_fmaxf(M, mbuf[s * kRows + n]);
+
+        if (!SAMPLE) {
+            // ---------------------------------------------------------- teacher forced: lse + picked log-prob
+            sbuf[sp * kRows + n] = (m_run == TG_NEG_INF) ? 0.0 : (double)c_grp * exp((double)(m_run - M));
+            __syncthreads();
+            if (tid < kRows) {
+                double S = 0.0;
+#pragma unroll
+                for (int s = 0; s < kNSpan; ++s) S += sbuf[s * kRows + n];
+                const float lse = (float)((double)M + log(S));
+                if (valid) {
+                    const size_t o = tf_row * L + t;
+                    if (a.lse_out) a.lse_out[o] = lse;
+                    if (a.target && a.logp_out) {
+                        const int tv = tg_min(tg_max((int)a.target[o], 0), V - 1);
+                        const float lg = dot_mfma_order(a.w.w_out + (size_t)tv * kH, hbuf + n * kHStride, a.w.b_out[tv]);
+                        a.logp_out[o] = lg - lse;
+                    }
+                }
+            }
+            if (t + 1 < L) tok = tg_min(tg_max((int)a.inp[tf_row * L + t + 1], 0), V - 1);
+            __syncthreads();
+            continue;
+        }
+
+        // ============================================================== canonical inverse-CDF draw
+        const int sp_hi = tg_min(V, sp_lo + Ls);
+        const int ng_valid = (sp_hi > sp_lo) ? (sp_hi - sp_lo + EG - 1) / EG : 0;
+        {
+            double s = 0.0;
+            for (int q = 0; q < ng_valid; ++q) {
+                const float2 r = rec[(q * kNSpan + sp) * kRows + n];
+                s += (double)r.y * exp((double)(r.x - M));
+            }
+            sbuf[sp * kRows + n] = s;
+        }
+        __syncthreads();
+        {
+            double S = 0.0;
+#pragma unroll
+            for (int s = 0; s < kNSpan; ++s) S += sbuf[s * kRows + n];
+            const double target = (double)u_base[(size_t)t * u_stride] * S;
+            int sel = last_span;
+            double p = 0.0;
+            for (int s = 0; s < kNSpan; ++s) {
+                const double ss = sbuf[s * kRows + n];
+                if (p + ss > target || s == last_span) { sel = s; break; }
+                p += ss;
+            }
+            if (sel == sp) {  // exactly one of the row's 8 threads owns the draw
+                int gq = ng_valid - 1;
+                for (int q = 0; q < ng_valid; ++q) {
+                    const float2 r = rec[(q * kNSpan + sp) * kRows + n];
+                    const double c = (double)r.y * exp((double)(r.x - M));
+                    if (p + c > target || q == ng_valid - 1) { gq = q; break; }
+                    p += c;
+                }
+                selv[n] = sp_lo + gq * EG;
+                selp[n] = p;
+                tgt[n] = target;
+                Mbuf[n] = M;
+            }
+        }
+        __syncthreads();
+        // cooperative recompute of the chosen groups: 32 rows x EG entries over 256 threads
+        for (int idx = tid; idx < kRows * EG; idx += kThreads) {
+            const int rr = idx / EG, e = idx - rr * EG;
+            const int gv = selv[rr];
+            const int vend = tg_min(V, (gv / Ls + 1) * Ls);
+            const int v = gv + e;
+            float wv = 0.f;
+            if (v < vend) {
+                const float lg = dot_mfma_order(a.w.w_out + (size_t)v * kH, hbuf + rr * kHStride, a.w.b_out[v]);
+                wv = tg_expf(lg - Mbuf[rr]);
+            }
+            wbuf[rr * (EG + 1) + e] = wv;
+        }
+        __syncthreads();
+        if (tid < kRows) {
+            const int gv = selv[n];
+            const int vend = tg_min(V, (gv / Ls + 1) * Ls);
+            const int g_hi = tg_min(vend, gv + EG);
+            const int nt_valid = (g_hi - gv + 15) / 16;
+            const double target = tgt[n];
+            double p = selp[n];
+            const float* wr = wbuf + n * (EG + 1);
+            int tq = nt_valid - 1;
+            for (int tt = 0; tt < nt_valid; ++tt) {
+                float ts = 0.f;
+                for (int r = 0; r < 16; ++r) ts += wr[tt * 16 + r];  // entries >= vend are 0
+                if (p + (double)ts > target || tt == nt_valid - 1) { tq = tt; break; }
+                p += (double)ts;
+            }
+            const int t_lo = gv + tq * 16;
+            const int t_hi = tg_min(g_hi, t_lo + 16);
+            int drawn = t_hi - 1;
+            float pp = 0.f;
+            for (int v = t_lo; v < t_hi; ++v) {
+                pp += wr[v - gv];
+                if (p + (double)pp > target) { drawn = v; break; }
+            }
+            if (valid) out_row[t] = drawn;
+            tokbuf[n] = forced_row ? tg_min(tg_max((int)forced_row[t], 0), V - 1) : drawn;
+        }
+        __syncthreads();
+        tok = tokbuf[n];
+    }
+}
+
+SamplerGeom make_geom(int V) {
+    SamplerGeom g;
+    g.Ls = 16 * ((V + kNSpan * 16 - 1) / (kNSpan * 16));
+    g.NT = g.Ls / 16;
+    g.GK = 1;
+    while ((g.NT + g.GK - 1) / g.GK > 16 && g.GK < 8) g.GK *= 2;
+    g.NG = (g.NT + g.GK - 1) / g.GK;
+    return g;
+}
+
+size_t smem_bytes(const SamplerGeom& g, bool sample) {
+    size_t b = sizeof(float) * kRows * kHStride + sizeof(float) * kNSpan * kRows + sizeof(double) * kNSpan * kRows +
+               sizeof(int) * kRows * 2 + sizeof(float) * kRows + sizeof(double) * kRows * 2;
+    if (sample) {
+        const int EG = g.GK * 16;
+        size_t wb = (size_t)kRows * (EG + 1);
+        wb += wb & 1;
+        b += sizeof(float) * wb + sizeof(float2) * (size_t)g.NG * kNSpan * kRows;
+    } else {
+        b += 16;
+    }
+    return b;
+}
+
+int check_weights(const TgGenWeights* w) {
+    if (!w || !w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out) {
+        tg_set_error("generator weights: null pointer");
+        return TG_ERR_ARG;
+    }
+    if (w->E != kH || w->H != kH) {
+        tg_set_error("generator shape E=%d H=%d not supported by this build (E=H=32 only)", w->E, w->H);
+        return TG_ERR_ARG;
+    }
+    if (w->V < 1) {
+        tg_set_error("generator vocab %d < 1", w->V);
+        return TG_ERR_ARG;
+    }
+    return TG_OK;
+}
+
+template <bool SAMPLE>
+int launch(const GenArgs& a, int grid, hipStream_t stream) {
+    const size_t sm = smem_bytes(a.geo, SAMPLE);
+    if (sm > 160 * 1024) {
+        tg_set_error("generator kernel needs %zu bytes of LDS (> 160 KiB)", sm);
+        return TG_ERR_ARG;
+    }
+    static thread_local size_t set_max[2] = {0, 0};
+    if (sm > 48 * 1024 && sm > set_max[SAMPLE]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        set_max[SAMPLE] = sm;
+    }
+    hipLaunchKernelGGL(k_gen<SAMPLE>, dim3(grid), dim3(kThreads), sm, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        tg_set_error("k_gen launch: %s", hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    return TG_OK;
+}
+
+}  // namespace
+
+extern "C" int tg_gen_supported(int V, int E, int H) { return (V >= 1 && E == kH && H == kH) ? 0 : -1; }
+
+extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                                     float* logp_out, float* lse_out, float* logits_out, float* states_out,
+                                     void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!inp || N < 0 || L < 1) {
+        tg_set_error("tg_gen_teacher_forced: bad arguments (N=%d L=%d)", N, L);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    GenArgs a = {};
+    a.w = *w;
+    a.geo = make_geom(w->V);
+    a.N = N;
+    a.L = L;
+    a.inp = inp;
+    a.target = target;
+    a.logp_out = logp_out;
+    a.lse_out = lse_out;
+    a.logits_out = logits_out;
+    a.states_out = states_out;
+    a.need_proj = ((target && logp_out) || lse_out || logits_out) ? 1 : 0;
+    return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
+}
+
+extern "C" size_t tg_gen_rollout_workspace_bytes(int B, int L, int H) {
+    return sizeof(float) * (size_t)(L + 1) * B * 2 * H;
+}
+
+extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int L, int R, int g_lo, int g_hi,
+                              int i_lo, int i_hi, const float* uniforms, const int64_t* forced, int64_t* completions,
+                              void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!sentences || !uniforms || !completions || B < 1 || L < 1 || R < 1 || g_lo < 1 || g_hi > L || g_lo > g_hi ||
+        i_lo < 0 || i_hi > R || i_lo > i_hi) {
+        tg_set_error("tg_gen_rollout: bad arguments (B=%d L=%d R=%d g=[%d,%d] i=[%d,%d))", B, L, R, g_lo, g_hi, i_lo,
+                     i_hi);
+        return TG_ERR_ARG;
+    }
+    if (i_lo == i_hi) return TG_OK;
+    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(B, L, kH)) {
+        tg_set_error("tg_gen_rollout: workspace too small (%zu < %zu)", workspace_bytes,
+                     tg_gen_rollout_workspace_bytes(B, L, kH));
+        return TG_ERR_WORKSPACE;
+    }
+    // 1) prefix states: teacher-forced pass over the sentences, no projection (rollout.py:35-38)
+    rc = tg_gen_teacher_forced(w, sentences, nullptr, B, L, nullptr, nullptr, nullptr, (float*)workspace, stream);
+    if (rc) return rc;
+    // 2) all completions; tiles ordered by given_num ascending (longest first)
+    GenArgs a = {};
+    a.w = *w;
+    a.geo = make_geom(w->V);
+    a.sentences = sentences;
+    a.states = (const float*)workspace;
+    a.uniforms = uniforms;
+    a.forced = forced;
+    a.out = completions;
+    a.rollout = 1;
+    a.B = B;
+    a.L = L;
+    a.R = R;
+    a.g_lo = g_lo;
+    a.i_lo = i_lo;
+    a.rows_g = (i_hi - i_lo) * B;
+    a.tiles_g = (a.rows_g + kRows - 1) / kRows;
+    const long grid = (long)a.tiles_g * (g_hi - g_lo + 1);
+    if (grid > 0x7fffffffL) {
+        tg_set_error("tg_gen_rollout: grid too large");
+        return TG_ERR_ARG;
+    }
+    return launch<true>(a, (int)grid, (hipStream_t)stream);
+}
+
+extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter, const float* uniforms,
+                             const int64_t* forced, int64_t* out, void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!uniforms || !out || N < 0 || L < 1 || start_letter < 0 || start_letter >= w->V) {
+        tg_set_error("tg_gen_sample: bad arguments (N=%d L=%d start=%lld)", N, L, (long long)start_letter);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    GenArgs a = {};
+    a.w = *w;
+    a.geo = make_geom(w->V);
+    a.uniforms = uniforms;
+    a.forced = forced;
+    a.out = out;
+    a.start_letter = start_letter;
+    a.rollout = 0;
+    a.N = N;
+    a.L = L;
+    return launch<true>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
+}

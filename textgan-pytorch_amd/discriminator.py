@@ -1,0 +1,20 @@
+"""Same-kernel surfaces of ``CNNDiscriminator`` (models/discriminator.py:40-64)."""
+import torch
+
+from . import ops
+
+
+def forward(dis, inp, dropout_uniforms=None):
+    """CNNDiscriminator.forward: logits [N, n_out].  Dropout follows dis.training like nn.Dropout."""
+    p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
+    with torch.no_grad():
+        du = dropout_uniforms
+        if p > 0 and du is None:
+            du = torch.rand(inp.shape[0], dis.feature_dim, dtype=torch.float32, device=inp.device)
+        return ops.dis_score(dis, inp, dropout_p=p, dropout_uniforms=du, want_reward=False, want_logits=True)["logits"]
+
+
+def get_feature(dis, inp):
+    """CNNDiscriminator.get_feature: highway features [N, F]."""
+    with torch.no_grad():
+        return ops.dis_score(dis, inp, want_reward=False, want_feature=True)["feature"]

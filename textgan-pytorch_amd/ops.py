@@ -1,0 +1,103 @@
+"""Tensor-level wrappers of the C ABI (one function per entry point).
+
+All tensors are CUDA (ROCm) tensors; work is enqueued on torch's current
+stream; outputs are allocated by torch and written by the HIP kernels.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+I64, F32 = torch.int64, torch.float32
+
+
+def _tokens(t, name):
+    if t.dtype != I64:
+        t = t.long()
+    return t.contiguous() if not t.is_contiguous() else t, name
+
+
+def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, want_logits=False, want_states=False):
+    """tg_gen_teacher_forced: LSTMGenerator.forward over [N,L] with zero initial state
+    (models/generator.py:40-60).  Returns dict(logp [N,L], lse [N,L], logits [N,L,V], states [L+1,N,2,H])."""
+    w, keep = _lib.gen_weights(gen)
+    inp, _ = _tokens(inp, "inp")
+    N, L = inp.shape
+    dev = inp.device
+    tgt = None if target is None else _tokens(target, "target")[0]
+    logp = torch.empty(N, L, dtype=F32, device=dev) if (want_logp and tgt is not None) else None
+    lse = torch.empty(N, L, dtype=F32, device=dev) if want_lse else None
+    logits = torch.empty(N, L, w.V, dtype=F32, device=dev) if want_logits else None
+    states = torch.empty(L + 1, N, 2, w.H, dtype=F32, device=dev) if want_states else None
+    _lib.check(_lib.lib().tg_gen_teacher_forced(
+        C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(tgt, I64, "target"), N, L,
+        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(logits), _lib.dev_ptr(states), _lib.stream_ptr()))
+    return {"logp": logp, "lse": lse, "logits": logits, "states": states}
+
+
+def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_lo=0, i_hi=None, out=None):
+    """tg_gen_rollout: every rollout_mc_search(sentences, g) of get_reward's loops
+    (utils/rollout.py:25-55,143-145).  uniforms [R,L,L,B]; returns completions [R,L,B,L] int64."""
+    w, keep = _lib.gen_weights(gen)
+    s, _ = _tokens(sentences, "sentences")
+    B, L = s.shape
+    g_hi = L if g_hi is None else g_hi
+    i_hi = R if i_hi is None else i_hi
+    if uniforms.numel() != R * L * L * B:
+        raise RuntimeError("textgan_hip: uniforms must have R*L*L*B = %d elements, got %d"
+                           % (R * L * L * B, uniforms.numel()))
+    comp = out if out is not None else torch.empty(R, L, B, L, dtype=I64, device=s.device)
+    nbytes = _lib.lib().tg_gen_rollout_workspace_bytes(B, L, w.H)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+    f = None if forced is None else _tokens(forced, "forced")[0]
+    _lib.check(_lib.lib().tg_gen_rollout(
+        C.byref(w), _lib.dev_ptr(s, I64, "sentences"), B, L, R, g_lo, g_hi, i_lo, i_hi,
+        _lib.dev_ptr(uniforms, F32, "uniforms"), _lib.dev_ptr(f, I64, "forced"), _lib.dev_ptr(comp, I64, "completions"),
+        _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return comp
+
+
+def gen_sample(gen, N, L, start_letter, uniforms, forced=None):
+    """tg_gen_sample: the step loop of LSTMGenerator.sample (models/generator.py:71-81) for N rows.
+    uniforms [L,N]; returns [N,L] int64 on the device."""
+    w, keep = _lib.gen_weights(gen)
+    if uniforms.numel() != L * N:
+        raise RuntimeError("textgan_hip: uniforms must have L*N = %d elements" % (L * N))
+    out = torch.empty(N, L, dtype=I64, device=uniforms.device)
+    f = None if forced is None else _tokens(forced, "forced")[0]
+    _lib.check(_lib.lib().tg_gen_sample(C.byref(w), N, L, int(start_letter), _lib.dev_ptr(uniforms, F32, "uniforms"),
+                                        _lib.dev_ptr(f, I64, "forced"), _lib.dev_ptr(out), _lib.stream_ptr()))
+    return out
+
+
+def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_reward=True, want_logits=False,
+              want_feature=False, reward_out=None, weights=None):
+    """tg_dis_score: CNNDiscriminator.forward (models/discriminator.py:40-64) + softmax column
+    (utils/rollout.py:146-148).  seqs [N,L]; returns dict(reward [N], logits [N,n_out], feature [N,F])."""
+    w, keep = weights if weights is not None else _lib.dis_weights(dis)
+    s, _ = _tokens(seqs, "seqs")
+    N, L = s.shape
+    dev = s.device
+    reward = reward_out if reward_out is not None else (torch.empty(N, dtype=F32, device=dev) if want_reward else None)
+    logits = torch.empty(N, w.n_out, dtype=F32, device=dev) if want_logits else None
+    feat = torch.empty(N, w.F, dtype=F32, device=dev) if want_feature else None
+    if dropout_p > 0.0 and dropout_uniforms is not None and dropout_uniforms.numel() != N * w.F:
+        raise RuntimeError("textgan_hip: dropout_uniforms must have N*F = %d elements" % (N * w.F))
+    nbytes = _lib.lib().tg_dis_workspace_bytes(C.byref(w), N, L)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().tg_dis_score(
+        C.byref(w), _lib.dev_ptr(s, I64, "seqs"), N, L, int(col), float(dropout_p),
+        _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms"), _lib.dev_ptr(reward), _lib.dev_ptr(logits),
+        _lib.dev_ptr(feat), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return {"reward": reward, "logits": logits, "feature": feat}
+
+
+def reward_reduce(raw, B, L, R):
+    """tg_reward_reduce: torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153)."""
+    if raw.numel() != R * L * B:
+        raise RuntimeError("textgan_hip: raw must have R*L*B elements")
+    out = torch.empty(B, L, dtype=F32, device=raw.device)
+    _lib.check(_lib.lib().tg_reward_reduce(_lib.dev_ptr(raw, F32, "raw"), B, L, R, _lib.dev_ptr(out),
+                                           _lib.stream_ptr()))
+    return out

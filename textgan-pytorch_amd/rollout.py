@@ -1,0 +1,137 @@
+"""Drop-in for the reference's ``utils.rollout.ROLLOUT`` (utils/rollout.py:15-154).
+
+Same constructor, same ``get_reward(sentences, rollout_num, dis, current_k=0)``
+signature and result ([B, L] float tensor on the input's device), same
+attributes.  The double Python loop over (rollout, given_num), the per-token
+``gen.forward`` / ``torch.multinomial`` launches and the per-prefix
+``dis.forward`` calls collapse into three HIP launches (prefix states, all
+completions, scorer) plus one RCCL all-gather when a process group is active.
+"""
+import copy
+
+import torch
+
+from . import _lib, dist as tdist, ops
+
+
+class ROLLOUT:
+    #: sequences scored per tg_dis_score call (bounds the pooled / dropout scratch)
+    dis_chunk = 1 << 17
+
+    def __init__(self, gen, gpu=True):
+        self.gen = gen
+        self._old_model = None          # reference deep-copies here (rollout.py:18) and never reads it
+        self.max_seq_len = gen.max_seq_len
+        self.vocab_size = gen.vocab_size
+        self.step_size = gen.step_size if getattr(gen, "name", None) == "leakgan" else 0
+        self.goal_out_size = gen.goal_out_size if getattr(gen, "name", None) == "leakgan" else 0
+        self.gpu = gpu
+        self.generator = None           # optional torch.Generator for the uniforms
+        self.group = None               # optional torch.distributed process group
+        self.timers = None              # optional dict name -> list[(start_event, end_event)]
+        _lib.lib()                      # fail loudly here if the HIP extension is missing
+
+    @property
+    def old_model(self):
+        if self._old_model is None:
+            self._old_model = copy.deepcopy(self.gen)
+        return self._old_model
+
+    # ------------------------------------------------------------------ helpers
+    def _timed(self, name):
+        return _Timed(self.timers, name)
+
+    def _check(self, sentences):
+        if not sentences.is_cuda:
+            raise RuntimeError("textgan_hip ROLLOUT: sentences must be on the GPU (got %s); there is no CPU path"
+                               % sentences.device)
+        if sentences.dim() != 2 or sentences.shape[1] != self.max_seq_len:
+            raise RuntimeError("textgan_hip ROLLOUT: sentences must be [batch, %d]" % self.max_seq_len)
+
+    def _rand(self, shape, device):
+        return torch.rand(shape, dtype=torch.float32, device=device, generator=self.generator)
+
+    # ------------------------------------------------------------------ reference API
+    def rollout_mc_search(self, sentences, given_num, uniforms=None):
+        """utils/rollout.py:25-55: keep ``given_num`` tokens, sample the rest. Returns [B, L] int64."""
+        self._check(sentences)
+        B, L = sentences.shape
+        if not (1 <= given_num <= L):
+            raise RuntimeError("given_num must be in [1, %d]" % L)
+        with torch.no_grad():
+            u = uniforms if uniforms is not None else self._rand((1, L, L, B), sentences.device)
+            comp = ops.gen_rollout(self.gen, sentences, 1, u, g_lo=given_num, g_hi=given_num)
+        return comp[0, given_num - 1]
+
+    def get_reward(self, sentences, rollout_num, dis, current_k=0, uniforms=None, dropout_uniforms=None,
+                   return_parts=False):
+        """utils/rollout.py:128-154.
+
+        uniforms          optional [R,L,L,B] pre-drawn U[0,1) (index [i, given_num-1, t, b]); drawn with
+                          torch.rand when omitted.  With a process group it is the GLOBAL tensor.
+        dropout_uniforms  optional [R*L, B, F] for the discriminator's live dropout (the reference never
+                          calls dis.eval(), so dropout is active whenever dis.training is True)."""
+        self._check(sentences)
+        R = int(rollout_num)
+        B, L = sentences.shape
+        dev = sentences.device
+        plan = tdist.ShardPlan.from_group(R, self.group)
+        Rl = plan.i_hi - plan.i_lo
+        with torch.no_grad():
+            if uniforms is None:
+                u = self._rand((Rl, L, L, B), dev)
+            else:
+                u = uniforms.reshape(R, L, L, B)[plan.i_lo:plan.i_hi].contiguous()
+            raw_local = torch.empty(Rl * L, B, dtype=torch.float32, device=dev)
+            comp = None
+            if Rl > 0:
+                with self._timed("gen_rollout"):
+                    comp = ops.gen_rollout(self.gen, sentences, Rl, u)
+                p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
+                weights = _lib.dis_weights(dis)
+                seqs = comp.view(Rl * L * B, L)
+                flat = raw_local.view(-1)
+                F = weights[0].F
+                du_all = None
+                if p > 0 and dropout_uniforms is not None:
+                    du_all = dropout_uniforms.reshape(R * L * B, F)[plan.i_lo * L * B:plan.i_hi * L * B]
+                with self._timed("dis_score"):
+                    for lo in range(0, seqs.shape[0], self.dis_chunk):
+                        hi = min(seqs.shape[0], lo + self.dis_chunk)
+                        du = None
+                        if p > 0:
+                            du = du_all[lo:hi].contiguous() if du_all is not None else self._rand((hi - lo, F), dev)
+                        ops.dis_score(dis, seqs[lo:hi], col=current_k + 1, dropout_p=p, dropout_uniforms=du,
+                                      reward_out=flat[lo:hi], weights=weights)
+            with self._timed("exchange"):
+                raw = tdist.gather_rows(raw_local, plan, L, self.group)
+            with self._timed("reduce"):
+                rewards = ops.reward_reduce(raw, B, L, R)
+        if return_parts:
+            return rewards, raw, comp
+        return rewards
+
+
+class _Timed:
+    def __init__(self, timers, name):
+        self.timers, self.name = timers, name
+
+    def __enter__(self):
+        if self.timers is not None:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if self.timers is not None:
+            self.e.record()
+            self.timers.setdefault(self.name, []).append((self.s, self.e))
+        return False
+
+
+def install(rollout_module):
+    """Replace ``ROLLOUT`` in the reference's ``utils.rollout`` module (and thereby in every
+    instructor that does ``from utils.rollout import ROLLOUT`` afterwards)."""
+    rollout_module.ROLLOUT = ROLLOUT
+    return ROLLOUT
