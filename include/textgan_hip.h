@@ -164,6 +164,20 @@ int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L,
 int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
                      void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Measurement hook (no counterpart in the reference): when enabled, every
+ * kernel launch is bracketed by hipEvents on its launch stream.
+ * tg_profile_read() synchronises on the recorded events of one kernel id,
+ * returns their summed duration and count, and forgets them. */
+#define TG_KERNEL_GEN_TEACHER 0   /* k_gen<false>: teacher-forced / prefix states */
+#define TG_KERNEL_GEN_SAMPLE 1    /* k_gen<true>:  rollout / sample               */
+#define TG_KERNEL_DIS_CONV 2      /* k_dis_conv                                   */
+#define TG_KERNEL_DIS_HIGHWAY 3   /* k_dis_highway                                */
+#define TG_KERNEL_DIS_FINAL 4     /* k_dis_final                                  */
+#define TG_KERNEL_REDUCE 5        /* k_reward_reduce                              */
+void tg_profile_enable(int on);
+int tg_profile_read(int kernel_id, double* total_ms, int* count);
+
 #ifdef __cplusplus
 }
 #endif

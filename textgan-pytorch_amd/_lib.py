@@ -15,7 +15,9 @@ MAX_OUT = 8
 
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample", "tg_dis_workspace_bytes",
-           "tg_dis_score", "tg_reward_reduce"]
+           "tg_dis_score", "tg_reward_reduce", "tg_profile_enable", "tg_profile_read"]
+
+KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5}
 
 
 class GenW(C.Structure):
@@ -55,6 +57,10 @@ def lib():
         l.tg_dis_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5 + \
                                   [C.c_size_t, C.c_void_p]
         l.tg_reward_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        l.tg_profile_enable.argtypes = [C.c_int]
+        l.tg_profile_enable.restype = None
+        l.tg_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+        l.tg_profile_read.restype = C.c_int
         for fn in ("tg_gen_supported", "tg_gen_teacher_forced", "tg_gen_rollout", "tg_gen_sample", "tg_dis_score",
                    "tg_reward_reduce"):
             getattr(l, fn).restype = C.c_int
@@ -144,3 +150,17 @@ def dis_weights(dis):
         raise RuntimeError("textgan_hip: discriminator parameter shapes are inconsistent")
     w.V, w.Ed, w.F, w.n_out = V, Ed, F, n_out
     return w, keep
+
+
+def profile_enable(on):
+    lib().tg_profile_enable(1 if on else 0)
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} since the last read; synchronises on the recorded events."""
+    out = {}
+    for name, kid in KERNELS.items():
+        ms, n = C.c_double(0.0), C.c_int(0)
+        check(lib().tg_profile_read(kid, C.byref(ms), C.byref(n)))
+        out[name] = (ms.value, n.value)
+    return out

@@ -2,6 +2,9 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <mutex>
+#include <vector>
+
 #include "tg_common.h"
 
 static thread_local char g_err[512] = "";
@@ -14,6 +17,62 @@ void tg_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* tg_last_error(void) { return g_err; }
+
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg)
+namespace {
+struct ProfRec { int id; hipEvent_t a, b; };
+std::mutex g_prof_mu;
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof_recs;
+std::vector<hipEvent_t> g_prof_pool;
+hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+}  // namespace
+
+void tg_prof_begin(int id, hipStream_t s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{id, prof_event(), prof_event()};
+    (void)hipEventRecord(r.a, s);
+    g_prof_recs.push_back(r);
+}
+void tg_prof_end(hipStream_t s) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().b, s);
+}
+
+extern "C" void tg_profile_enable(int on) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = on != 0;
+}
+
+extern "C" int tg_profile_read(int id, double* total_ms, int* count) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    double tot = 0.0;
+    int n = 0;
+    std::vector<ProfRec> keep;
+    for (const ProfRec& r : g_prof_recs) {
+        if (r.id != id) { keep.push_back(r); continue; }
+        float ms = 0.f;
+        if (hipEventSynchronize(r.b) != hipSuccess || hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) {
+            tg_set_error("tg_profile_read: event query failed");
+            return TG_ERR_LAUNCH;
+        }
+        tot += ms;
+        ++n;
+        g_prof_pool.push_back(r.a);
+        g_prof_pool.push_back(r.b);
+    }
+    g_prof_recs.swap(keep);
+    if (total_ms) *total_ms = tot;
+    if (count) *count = n;
+    return TG_OK;
+}
 extern "C" const char* tg_version(void) { return "textgan_hip 0.1 gfx950"; }
 
 // torch.mean(rewards.view(B, L, R), dim=-1) on the flat [R*L, B] buffer (utils/rollout.py:153):
@@ -33,7 +92,9 @@ extern "C" int tg_reward_reduce(const float* raw, int B, int L, int R, float* ou
         return TG_ERR_ARG;
     }
     const int BL = B * L;
+    tg_prof_begin(TG_KERNEL_REDUCE, (hipStream_t)stream);
     hipLaunchKernelGGL(k_reward_reduce, dim3((BL + 255) / 256), dim3(256), 0, (hipStream_t)stream, raw, BL, R, out);
+    tg_prof_end((hipStream_t)stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         tg_set_error("k_reward_reduce launch: %s", hipGetErrorString(e));

@@ -39,5 +39,7 @@ __device__ __forceinline__ float tg_tanh(float x) {
 __device__ __forceinline__ int tg_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int tg_max(int a, int b) { return a > b ? a : b; }
 
-// host-side error plumbing (tg_api.cpp)
+// host-side error plumbing and per-kernel event timing (tg_api.hip)
 void tg_set_error(const char* fmt, ...);
+void tg_prof_begin(int kernel_id, hipStream_t s);
+void tg_prof_end(hipStream_t s);

@@ -462,7 +462,9 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
         }
         conv_set = sm;
     }
+    tg_prof_begin(TG_KERNEL_DIS_CONV, stream);
     hipLaunchKernelGGL(k_dis_conv, dim3((N + S - 1) / S), dim3(kConvThreads), sm, stream, ca);
+    tg_prof_end(stream);
 
     // ---- highway + gate + dropout + partial logits
     HwArgs ha = {};
@@ -476,7 +478,9 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
     ha.N = N;
     ha.nchunk = nchunk;
     ha.nseqtile = (N + kHwTile - 1) / kHwTile;
+    tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
     hipLaunchKernelGGL(k_dis_highway, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, ha);
+    tg_prof_end(stream);
 
     // ---- final: fixed-order partial sum, softmax column
     FinalArgs fa = {};
@@ -488,7 +492,9 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
     fa.nchunk = nchunk;
     fa.n_out = w->n_out;
     fa.col = col;
+    tg_prof_begin(TG_KERNEL_DIS_FINAL, stream);
     hipLaunchKernelGGL(k_dis_final, dim3((N + 255) / 256), dim3(256), 0, stream, fa);
+    tg_prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         tg_set_error("tg_dis_score launch: %s", hipGetErrorString(e));

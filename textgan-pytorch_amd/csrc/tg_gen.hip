@@ -481,7 +481,9 @@ int launch(const GenArgs& a, int grid, hipStream_t stream) {
         }
         set_max[SAMPLE] = sm;
     }
+    tg_prof_begin(SAMPLE ? TG_KERNEL_GEN_SAMPLE : TG_KERNEL_GEN_TEACHER, stream);
     hipLaunchKernelGGL(k_gen<SAMPLE>, dim3(grid), dim3(kThreads), sm, stream, a);
+    tg_prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         tg_set_error("k_gen launch: %s", hipGetErrorString(e));
