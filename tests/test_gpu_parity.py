@@ -227,6 +227,6 @@ def test_errors_and_cpu_inputs():
     gen = tg.modules.synthetic_generator(100, 32, 32, 20, device=DEV)
     with pytest.raises(RuntimeError):
         tg.ROLLOUT(gen).get_reward(torch.zeros(4, 20, dtype=torch.long), 2, None)  # CPU tensor
-    bad = tg.modules.LSTMGenerator(48, 48, 100, 20).to(DEV)
+    bad = tg.modules.LSTMGenerator(48, 96, 100, 20).to(DEV)  # H not in {32,64,128,256,512}
     with pytest.raises(RuntimeError):
         tg.ops.gen_sample(bad, 4, 20, 1, torch.rand(20, 4, device=DEV))

@@ -15,15 +15,18 @@
 // Logits never touch HBM.  Replaces models/generator.py:40-84, utils/rollout.py:25-55 and
 // the forward inside metrics/nll.py:59-61 of the reference.
 //
-// This file implements E = H = 32 (SeqGAN / SentiGAN / MaliGAN / oracle configs).
+// Two operand placements, one kernel body (template <SAMPLE, HT = H/32, REG>):
+//   REG  (E = H = 32, every SeqGAN / SentiGAN / MaliGAN / oracle config of the reference):
+//        gate weights and the h / x B-operands stay in VGPRs for the whole kernel;
+//   !REG (H in {32,64,128,256,512}, E any multiple of 32 -- the scaled config): h and the
+//        step's embedded inputs live in LDS ([32][H+4], [32][E+4]), gate weights stream from L2;
+//        each wave owns H/32 gate tiles (its c state: H/8 VGPRs).
 #include "tg_common.h"
 
 namespace {
 
-constexpr int kH = 32;        // hidden = embedding dim handled by this kernel
 constexpr int kRows = 32;     // rows per workgroup (MFMA N)
 constexpr int kThreads = 256; // 4 waves
-constexpr int kHStride = 36;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
 constexpr int kNSpan = 8;
 
 struct SamplerGeom {
@@ -57,37 +60,62 @@ struct GenArgs {
     int need_proj;
 };
 
-// One row of W_out (32 floats) dotted with h in the MFMA's own k order
-// (k pairs (j, 16+j), j = 0..15, starting from the bias), so that a recomputed
-// logit reproduces the MFMA result.
+
+// One row of W_out (H floats) dotted with h in the MFMA's own k order (per 32-wide chunk the
+// k pairs (j, 16+j), j = 0..15, starting from the bias), so that a recomputed logit reproduces
+// the MFMA result.
+template <int HT>
 __device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, const float* hrow, float bias) {
     float acc = bias;
-    const f32x4* w4 = reinterpret_cast<const f32x4*>(wrow);
-    f32x4 wl[4], wh[4];
+#pragma unroll 2
+    for (int c = 0; c < HT; ++c) {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(wrow + 32 * c);
+        f32x4 wl[4], wh[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { wl[i] = w4[i]; wh[i] = w4[4 + i]; }
+        for (int i = 0; i < 4; ++i) { wl[i] = w4[i]; wh[i] = w4[4 + i]; }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        acc = __builtin_fmaf(wl[j >> 2][j & 3], hrow[j], acc);
-        acc = __builtin_fmaf(wh[j >> 2][j & 3], hrow[16 + j], acc);
+        for (int j = 0; j < 16; ++j) {
+            acc = __builtin_fmaf(wl[j >> 2][j & 3], hrow[32 * c + j], acc);
+            acc = __builtin_fmaf(wh[j >> 2][j & 3], hrow[32 * c + 16 + j], acc);
+        }
     }
     return acc;
 }
 
-template <bool SAMPLE>
+// 16 consecutive floats (64 B, 16-B aligned) -> registers
+__device__ __forceinline__ void load16(const float* p, float (&dst)[16]) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(p);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = p4[q];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dst[4 * q + e] = v[e];
+    }
+}
+
+__device__ __forceinline__ int clamp_tok(int64_t t, int V) { return tg_min(tg_max((int)t, 0), V - 1); }
+
+template <bool SAMPLE, int HT, bool REG>
 __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
+    constexpr int kH = 32 * HT;
+    constexpr int kHStride = kH + 4;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
+    static_assert(!REG || HT == 1, "register-resident operands need H = 32");
+    const int E = REG ? 32 : a.w.E;
+    const int ET = E >> 5;
+    const int kEStride = E + 4;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* hbuf = reinterpret_cast<float*>(smem);                 // [32][36]
-    float* mbuf = hbuf + kRows * kHStride;                         // [8][32]
-    double* sbuf = reinterpret_cast<double*>(mbuf + kNSpan * kRows);  // [8][32]
-    int* tokbuf = reinterpret_cast<int*>(sbuf + kNSpan * kRows);   // [32]
-    int* selv = tokbuf + kRows;                                    // [32] chosen group's first vocab id
-    float* Mbuf = reinterpret_cast<float*>(selv + kRows);          // [32] row max
-    double* selp = reinterpret_cast<double*>(Mbuf + kRows);        // [32] prefix before the group
-    double* tgt = selp + kRows;                                    // [32] target = u*S
-    float* wbuf = reinterpret_cast<float*>(tgt + kRows);           // [32][EG+1] recomputed weights
+    float* hbuf = reinterpret_cast<float*>(smem);                     // [32][H+4]
+    float* mbuf = hbuf + kRows * kHStride;                             // [8][32]
+    double* sbuf = reinterpret_cast<double*>(mbuf + kNSpan * kRows);   // [8][32]
+    int* tokbuf = reinterpret_cast<int*>(sbuf + kNSpan * kRows);       // [32] next input token per row
+    int* selv = tokbuf + kRows;                                        // [32] chosen group's first vocab id
+    float* Mbuf = reinterpret_cast<float*>(selv + kRows);              // [32] row max
+    double* selp = reinterpret_cast<double*>(Mbuf + kRows);            // [32] prefix before the group
+    double* tgt = selp + kRows;                                        // [32] target = u*S
+    float* wbuf = reinterpret_cast<float*>(tgt + kRows);               // [32][EG+1] recomputed weights
+    float* xbuf = wbuf;                                                // !REG: [32][E+4] step inputs (aliases wbuf/rec)
     const int EG = a.geo.GK * 16;
-    float2* rec = reinterpret_cast<float2*>(wbuf + kRows * (EG + 1) + ((kRows * (EG + 1)) & 1));  // [NG][8][32]
+    float2* rec = reinterpret_cast<float2*>(wbuf + kRows * (EG + 1));  // [NG][8][32] (32*(EG+1) is even)
 
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -125,7 +153,7 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
             if (valid)
                 for (int s = sp; s < g; s += kNSpan) out_row[s] = a.sentences[(size_t)b * L + s];
             if (g >= L) return;  // given_num == L: the sentence itself (uniform per workgroup)
-            tok = (int)a.sentences[(size_t)b * L + g - 1];
+            tok = clamp_tok(a.sentences[(size_t)b * L + g - 1], V);
             state0 = a.states + ((size_t)(g - 1) * a.B + b) * 2 * kH;
         } else {
             const int fr = blockIdx.x * kRows + n;
@@ -135,62 +163,54 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
             forced_row = a.forced ? a.forced + (size_t)frc * L : nullptr;
             u_base = a.uniforms + frc;
             u_stride = a.N;
-            tok = (int)a.start_letter;
+            tok = clamp_tok(a.start_letter, V);
         }
     } else {
         const int fr = blockIdx.x * kRows + n;
         valid = fr < a.N;
         tf_row = valid ? fr : a.N - 1;
-        tok = (int)a.inp[tf_row * L];
+        tok = clamp_tok(a.inp[tf_row * L], V);  // ids must be < V; clamped for memory safety
         if (a.states_out && valid && w == 0) {  // slot 0 = zeros
             float* s0 = a.states_out + tf_row * 2 * kH;
             for (int k = hh * kH; k < hh * kH + kH; ++k) s0[k] = 0.f;
         }
     }
+    if (sp == 0) tokbuf[n] = tok;
 
-    tok = tg_min(tg_max(tok, 0), V - 1);  // ids must be < V; clamped for memory safety
-
-    // ------------------------------------------------------------------ resident weights
-    // gate tile of wave w: tile row i -> gate i>>3, unit 8w + (i&7)
+    // ------------------------------------------------------------------ resident weights (REG)
+    // gate tile T covers hidden units [8T, 8T+8): tile row i -> gate i>>3, unit 8T + (i&7), so that
+    // D reg r of lane (n, hh) is gate r>>2 of unit 8T + 4hh + (r&3): i,f,g,o of a unit share a lane.
     float wih[16], whh[16];
-    {
+    f32x16 gbias;
+    if constexpr (REG) {
         const int i = lane & 31;
         const int grow = (i >> 3) * kH + 8 * w + (i & 7);
-        const f32x4* pi = reinterpret_cast<const f32x4*>(a.w.w_ih + (size_t)grow * kH + 16 * hh);
-        const f32x4* ph = reinterpret_cast<const f32x4*>(a.w.w_hh + (size_t)grow * kH + 16 * hh);
+        load16(a.w.w_ih + (size_t)grow * 32 + 16 * hh, wih);
+        load16(a.w.w_hh + (size_t)grow * kH + 16 * hh, whh);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 vi = pi[q], vh = ph[q];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { wih[4 * q + e] = vi[e]; whh[4 * q + e] = vh[e]; }
+        for (int r = 0; r < 16; ++r) {
+            const int gr = (r >> 2) * kH + 8 * w + 4 * hh + (r & 3);
+            gbias[r] = a.w.b_ih[gr] + a.w.b_hh[gr];
         }
-    }
-    f32x16 gbias;  // D reg r: gate r>>2, unit 8w + 4hh + (r&3)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int grow = (r >> 2) * kH + 8 * w + 4 * hh + (r & 3);
-        gbias[r] = a.w.b_ih[grow] + a.w.b_hh[grow];
     }
 
     // ------------------------------------------------------------------ initial state
-    const int ubase = 8 * w + 4 * hh;  // this lane's 4 hidden units
-    f32x4 c4 = {0.f, 0.f, 0.f, 0.f};
-    {
+    // wave w owns gate tiles w*HT .. w*HT+HT-1; this lane's units of tile j: 8*(w*HT+j) + 4hh + 0..3
+    f32x4 c4[HT];
+#pragma unroll
+    for (int j = 0; j < HT; ++j) {
+        const int ub = 8 * (w * HT + j) + 4 * hh;
         f32x4 h4 = {0.f, 0.f, 0.f, 0.f};
+        c4[j] = h4;
         if (state0) {
-            h4 = *reinterpret_cast<const f32x4*>(state0 + ubase);
-            c4 = *reinterpret_cast<const f32x4*>(state0 + kH + ubase);
+            h4 = *reinterpret_cast<const f32x4*>(state0 + ub);
+            c4[j] = *reinterpret_cast<const f32x4*>(state0 + kH + ub);
         }
-        *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ubase) = h4;
+        *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ub) = h4;
     }
     __syncthreads();
-    float hb[16];  // MFMA B operand: h[n][16hh + j]
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(hbuf + n * kHStride + 16 * hh + 4 * q);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) hb[4 * q + e] = v[e];
-    }
+    float hb[16];  // REG: MFMA B operand h[n][16hh + j], kept in registers
+    if constexpr (REG) load16(hbuf + n * kHStride + 16 * hh, hb);
     __syncthreads();  // everyone has read hbuf before the first cell overwrites it
 
     // A-operand row of this lane in the projection tiles
@@ -201,15 +221,9 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
 
     for (int t = t0; t < L; ++t) {
         // ============================================================== LSTM cell
-        {
+        if constexpr (REG) {
             float xb[16];
-            const f32x4* px = reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tok * kH + 16 * hh);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = px[q];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) xb[4 * q + e] = v[e];
-            }
+            load16(a.w.emb + (size_t)tok * 32 + 16 * hh, xb);
             f32x16 acc = gbias;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc = TG_MFMA32(wih[j], xb[j], acc);
@@ -222,26 +236,82 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
                 const float fg = tg_sigmoid(acc[4 + e]);
                 const float gg = tg_tanh(acc[8 + e]);
                 const float og = tg_sigmoid(acc[12 + e]);
-                const float cn = fg * c4[e] + ig * gg;
-                c4[e] = cn;
+                const float cn = fg * c4[0][e] + ig * gg;
+                c4[0][e] = cn;
                 h4[e] = og * tg_tanh(cn);
             }
-            *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ubase) = h4;
+            const int ub = 8 * w + 4 * hh;
+            *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ub) = h4;  // old h is only in registers by now
             if (!SAMPLE && a.states_out && valid) {
                 float* st = a.states_out + ((size_t)(t + 1) * a.N + tf_row) * 2 * kH;
-                *reinterpret_cast<f32x4*>(st + ubase) = h4;
-                *reinterpret_cast<f32x4*>(st + kH + ubase) = c4;
+                *reinterpret_cast<f32x4*>(st + ub) = h4;
+                *reinterpret_cast<f32x4*>(st + kH + ub) = c4[0];
             }
-        }
-        __syncthreads();
+            __syncthreads();
+            load16(hbuf + n * kHStride + 16 * hh, hb);
+        } else {
+            // stage the step's embedded inputs: xbuf[r][:] = emb[tokbuf[r]]
+            const int e4 = E >> 2;
+            for (int idx = tid; idx < kRows * e4; idx += kThreads) {
+                const int r = idx / e4, c = idx - r * e4;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tokbuf[r] * E + 4 * c);
+                *reinterpret_cast<f32x4*>(xbuf + r * kEStride + 4 * c) = v;
+            }
+            __syncthreads();
+            f32x4 hnew[HT];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(hbuf + n * kHStride + 16 * hh + 4 * q);
+            for (int j = 0; j < HT; ++j) {
+                const int T = w * HT + j;
+                const int i = lane & 31;
+                const int grow = (i >> 3) * kH + 8 * T + (i & 7);
+                f32x16 acc;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) hb[4 * q + e] = v[e];
+                for (int r = 0; r < 16; ++r) {
+                    const int gr = (r >> 2) * kH + 8 * T + 4 * hh + (r & 3);
+                    acc[r] = a.w.b_ih[gr] + a.w.b_hh[gr];
+                }
+                float av[16], bv[16];
+                for (int c = 0; c < ET; ++c) {
+                    load16(a.w.w_ih + (size_t)grow * E + 32 * c + 16 * hh, av);
+                    load16(xbuf + n * kEStride + 32 * c + 16 * hh, bv);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc = TG_MFMA32(av[k], bv[k], acc);
+                }
+                for (int c = 0; c < HT; ++c) {
+                    load16(a.w.w_hh + (size_t)grow * kH + 32 * c + 16 * hh, av);
+                    load16(hbuf + n * kHStride + 32 * c + 16 * hh, bv);
+#pragma unroll
+                    for (int k = 0; k < 16; ++k) acc = TG_MFMA32(av[k], bv[k], acc);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ig = tg_sigmoid(acc[e]);
+                    const float fg = tg_sigmoid(acc[4 + e]);
+                    const float gg = tg_tanh(acc[8 + e]);
+                    const float og = tg_sigmoid(acc[12 + e]);
+                    const float cn = fg * c4[j][e] + ig * gg;
+                    c4[j][e] = cn;
+                    hnew[j][e] = og * tg_tanh(cn);
+                }
+            }
+            __syncthreads();  // every wave is done reading the old h (and xbuf)
+#pragma unroll
+            for (int j = 0; j < HT; ++j) {
+                const int ub = 8 * (w * HT + j) + 4 * hh;
+                *reinterpret_cast<f32x4*>(hbuf + n * kHStride + ub) = hnew[j];
+                if (!SAMPLE && a.states_out && valid) {
+                    float* st = a.states_out + ((size_t)(t + 1) * a.N + tf_row) * 2 * kH;
+                    *reinterpret_cast<f32x4*>(st + ub) = hnew[j];
+                    *reinterpret_cast<f32x4*>(st + kH + ub) = c4[j];
+                }
+            }
+            __syncthreads();
         }
         if (!SAMPLE && !a.need_proj) {
-            if (t + 1 < L) tok = tg_min(tg_max((int)a.inp[tf_row * L + t + 1], 0), V - 1);
+            if (t + 1 < L) {
+                tok = clamp_tok(a.inp[tf_row * L + t + 1], V);
+                if (sp == 0) tokbuf[n] = tok;
+            }
             __syncthreads();
             continue;
         }
@@ -252,19 +322,8 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
         const int sp_lo = sp * Ls;
         {
             float a_cur[16], a_nxt[16] = {};
-            auto load_a = [&](int q, float (&dst)[16]) {
-                const int v = tg_min(a_sp * Ls + 16 * q + a_r, V - 1);
-                const f32x4* p = reinterpret_cast<const f32x4*>(a.w.w_out + (size_t)v * kH + 16 * hh);
-#pragma unroll
-                for (int qq = 0; qq < 4; ++qq) {
-                    const f32x4 vv = p[qq];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) dst[4 * qq + e] = vv[e];
-                }
-            };
-            load_a(0, a_cur);
+            if constexpr (REG) load16(a.w.w_out + (size_t)tg_min(a_sp * Ls + a_r, V - 1) * kH + 16 * hh, a_cur);
             for (int q = 0; q < NT; ++q) {
-                if (q + 1 < NT) load_a(q + 1, a_nxt);
                 const int vb = sp_lo + 16 * q;
                 f32x16 acc;
                 if (vb + 16 <= V) {
@@ -279,8 +338,23 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[r] = a.w.b_out[tg_min(vb + r, V - 1)];
                 }
+                if constexpr (REG) {
+                    if (q + 1 < NT)
+                        load16(a.w.w_out + (size_t)tg_min(a_sp * Ls + 16 * (q + 1) + a_r, V - 1) * kH + 16 * hh, a_nxt);
 #pragma unroll
-                for (int j = 0; j < 16; ++j) acc = TG_MFMA32(a_cur[j], hb[j], acc);
+                    for (int j = 0; j < 16; ++j) acc = TG_MFMA32(a_cur[j], hb[j], acc);
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
+                } else {
+                    const float* wrow = a.w.w_out + (size_t)tg_min(a_sp * Ls + 16 * q + a_r, V - 1) * kH + 16 * hh;
+                    const float* hrow = hbuf + n * kHStride + 16 * hh;
+                    for (int c = 0; c < HT; ++c) {
+                        load16(wrow + 32 * c, a_cur);
+                        load16(hrow + 32 * c, a_nxt);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(a_cur[j], a_nxt[j], acc);
+                    }
+                }
                 const int nvalid = tg_max(0, tg_min(16, V - vb));
                 if (!SAMPLE && a.logits_out && valid) {
                     float* lo = a.logits_out + (tf_row * L + t) * (size_t)V + vb;
@@ -306,8 +380,6 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
                 m_run = m_new;
                 if (SAMPLE && ((q % GK == GK - 1) || q == NT - 1))
                     rec[((q / GK) * kNSpan + sp) * kRows + n] = make_float2(m_run, c_grp);
-#pragma unroll
-                for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
             }
         }
         mbuf[sp * kRows + n] = m_run;
@@ -329,13 +401,17 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
                     const size_t o = tf_row * L + t;
                     if (a.lse_out) a.lse_out[o] = lse;
                     if (a.target && a.logp_out) {
-                        const int tv = tg_min(tg_max((int)a.target[o], 0), V - 1);
-                        const float lg = dot_mfma_order(a.w.w_out + (size_t)tv * kH, hbuf + n * kHStride, a.w.b_out[tv]);
+                        const int tv = clamp_tok(a.target[o], V);
+                        const float lg =
+                            dot_mfma_order<HT>(a.w.w_out + (size_t)tv * kH, hbuf + n * kHStride, a.w.b_out[tv]);
                         a.logp_out[o] = lg - lse;
                     }
                 }
             }
-            if (t + 1 < L) tok = tg_min(tg_max((int)a.inp[tf_row * L + t + 1], 0), V - 1);
+            if (t + 1 < L) {
+                tok = clamp_tok(a.inp[tf_row * L + t + 1], V);
+                if (sp == 0) tokbuf[n] = tok;
+            }
             __syncthreads();
             continue;
         }
@@ -378,7 +454,7 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
                 Mbuf[n] = M;
             }
         }
-        __syncthreads();
+        __syncthreads();  // selections visible; every read of rec is done (wbuf / xbuf alias-free from here)
         // cooperative recompute of the chosen groups: 32 rows x EG entries over 256 threads
         for (int idx = tid; idx < kRows * EG; idx += kThreads) {
             const int rr = idx / EG, e = idx - rr * EG;
@@ -387,7 +463,7 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
             const int v = gv + e;
             float wv = 0.f;
             if (v < vend) {
-                const float lg = dot_mfma_order(a.w.w_out + (size_t)v * kH, hbuf + rr * kHStride, a.w.b_out[v]);
+                const float lg = dot_mfma_order<HT>(a.w.w_out + (size_t)v * kH, hbuf + rr * kHStride, a.w.b_out[v]);
                 wv = tg_expf(lg - Mbuf[rr]);
             }
             wbuf[rr * (EG + 1) + e] = wv;
@@ -417,7 +493,7 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
                 if (p + (double)pp > target) { drawn = v; break; }
             }
             if (valid) out_row[t] = drawn;
-            tokbuf[n] = forced_row ? tg_min(tg_max((int)forced_row[t], 0), V - 1) : drawn;
+            tokbuf[n] = forced_row ? clamp_tok(forced_row[t], V) : drawn;
         }
         __syncthreads();
         tok = tokbuf[n];
@@ -434,18 +510,21 @@ SamplerGeom make_geom(int V) {
     return g;
 }
 
-size_t smem_bytes(const SamplerGeom& g, bool sample) {
-    size_t b = sizeof(float) * kRows * kHStride + sizeof(float) * kNSpan * kRows + sizeof(double) * kNSpan * kRows +
+bool is_reg(int E, int H) { return E == 32 && H == 32; }
+
+size_t smem_bytes(const SamplerGeom& g, bool sample, int E, int H) {
+    size_t b = sizeof(float) * kRows * (H + 4) + sizeof(float) * kNSpan * kRows + sizeof(double) * kNSpan * kRows +
                sizeof(int) * kRows * 2 + sizeof(float) * kRows + sizeof(double) * kRows * 2;
+    size_t region = 16;
     if (sample) {
         const int EG = g.GK * 16;
-        size_t wb = (size_t)kRows * (EG + 1);
-        wb += wb & 1;
-        b += sizeof(float) * wb + sizeof(float2) * (size_t)g.NG * kNSpan * kRows;
-    } else {
-        b += 16;
+        region = sizeof(float) * (size_t)kRows * (EG + 1) + sizeof(float2) * (size_t)g.NG * kNSpan * kRows;
     }
-    return b;
+    if (!is_reg(E, H)) {
+        const size_t xb = sizeof(float) * (size_t)kRows * (E + 4);
+        region = region > xb ? region : xb;
+    }
+    return b + region;
 }
 
 int check_weights(const TgGenWeights* w) {
@@ -453,36 +532,34 @@ int check_weights(const TgGenWeights* w) {
         tg_set_error("generator weights: null pointer");
         return TG_ERR_ARG;
     }
-    if (w->E != kH || w->H != kH) {
-        tg_set_error("generator shape E=%d H=%d not supported by this build (E=H=32 only)", w->E, w->H);
-        return TG_ERR_ARG;
-    }
-    if (w->V < 1) {
-        tg_set_error("generator vocab %d < 1", w->V);
+    if (tg_gen_supported(w->V, w->E, w->H) != 0) {
+        tg_set_error("generator shape V=%d E=%d H=%d not supported by this build "
+                     "(H in {32,64,128,256,512}, E a multiple of 32 up to 512)", w->V, w->E, w->H);
         return TG_ERR_ARG;
     }
     return TG_OK;
 }
 
-template <bool SAMPLE>
-int launch(const GenArgs& a, int grid, hipStream_t stream) {
-    const size_t sm = smem_bytes(a.geo, SAMPLE);
+template <bool SAMPLE, int HT, bool REG>
+int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
+    const size_t sm = smem_bytes(a.geo, SAMPLE, a.w.E, a.w.H);
     if (sm > 160 * 1024) {
-        tg_set_error("generator kernel needs %zu bytes of LDS (> 160 KiB)", sm);
+        tg_set_error("generator kernel needs %zu bytes of LDS (> 160 KiB) for V=%d E=%d H=%d", sm, a.w.V, a.w.E,
+                     a.w.H);
         return TG_ERR_ARG;
     }
-    static thread_local size_t set_max[2] = {0, 0};
-    if (sm > 48 * 1024 && sm > set_max[SAMPLE]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE>),
+    static thread_local size_t set_max = 0;
+    if (sm > 48 * 1024 && sm > set_max) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
             return TG_ERR_LAUNCH;
         }
-        set_max[SAMPLE] = sm;
+        set_max = sm;
     }
     tg_prof_begin(SAMPLE ? TG_KERNEL_GEN_SAMPLE : TG_KERNEL_GEN_TEACHER, stream);
-    hipLaunchKernelGGL(k_gen<SAMPLE>, dim3(grid), dim3(kThreads), sm, stream, a);
+    hipLaunchKernelGGL((k_gen<SAMPLE, HT, REG>), dim3(grid), dim3(kThreads), sm, stream, a);
     tg_prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -492,10 +569,26 @@ int launch(const GenArgs& a, int grid, hipStream_t stream) {
     return TG_OK;
 }
 
+template <bool SAMPLE>
+int launch(const GenArgs& a, int grid, hipStream_t stream) {
+    if (is_reg(a.w.E, a.w.H)) return launch_t<SAMPLE, 1, true>(a, grid, stream);
+    switch (a.w.H) {
+        case 32: return launch_t<SAMPLE, 1, false>(a, grid, stream);
+        case 64: return launch_t<SAMPLE, 2, false>(a, grid, stream);
+        case 128: return launch_t<SAMPLE, 4, false>(a, grid, stream);
+        case 256: return launch_t<SAMPLE, 8, false>(a, grid, stream);
+        case 512: return launch_t<SAMPLE, 16, false>(a, grid, stream);
+    }
+    tg_set_error("generator hidden size %d not compiled", a.w.H);
+    return TG_ERR_ARG;
+}
+
 }  // namespace
 
-extern "C" int tg_gen_supported(int V, int E, int H) { return (V >= 1 && E == kH && H == kH) ? 0 : -1; }
-
+extern "C" int tg_gen_supported(int V, int E, int H) {
+    const bool h_ok = H == 32 || H == 64 || H == 128 || H == 256 || H == 512;
+    return (V >= 1 && h_ok && E >= 32 && E <= 512 && (E % 32) == 0) ? 0 : -1;
+}
 extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
                                      float* logp_out, float* lse_out, float* logits_out, float* states_out,
                                      void* stream) {
@@ -537,9 +630,9 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
         return TG_ERR_ARG;
     }
     if (i_lo == i_hi) return TG_OK;
-    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(B, L, kH)) {
+    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(B, L, w->H)) {
         tg_set_error("tg_gen_rollout: workspace too small (%zu < %zu)", workspace_bytes,
-                     tg_gen_rollout_workspace_bytes(B, L, kH));
+                     tg_gen_rollout_workspace_bytes(B, L, w->H));
         return TG_ERR_WORKSPACE;
     }
     // 1) prefix states: teacher-forced pass over the sentences, no projection (rollout.py:35-38)

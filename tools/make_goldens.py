@@ -237,10 +237,17 @@ def main():
     run_get_reward("reward_c1_r2", 5000, 32, 32, 20, 64, 2, "seqgan", 0, 1.0, 0, 1, 2)
     run_get_reward("reward_c2_r1", 5255, 32, 32, 51, 64, 1, "seqgan", 3, 1.0, 3, 4, 5)
     run_get_reward("reward_c1_flat_r1", 5000, 32, 32, 20, 64, 1, "seqgan", 5, 0.1, 6, 7, 8)
+    # larger generators (the scaled config's E = H = 512 at small V / B, and E != H)
+    run_get_reward("reward_h64", 300, 64, 64, 20, 8, 2, "seqgan", 91, 0.3, 92, 93, 94)
+    run_get_reward("reward_e32_h128", 260, 32, 128, 20, 6, 2, "seqgan", 95, 0.15, 96, 97, 98)
+    run_get_reward("reward_e96_h32", 200, 96, 32, 20, 5, 2, "seqgan", 99, 0.3, 100, 101, 102)
+    run_get_reward("reward_h512", 1000, 512, 512, 20, 4, 1, "seqgan", 103, 0.05, 104, 105, 106)
     # forward / NLL
     run_forward_nll("nll_tiny", 200, 32, 32, 20, 43, 8, 61, 1.0, 62, save_logits=True)
     run_forward_nll("nll_c5_slice", 5000, 32, 32, 20, 200, 64, 0, 1.0, 63, save_logits=False)
+    run_forward_nll("nll_h256", 500, 256, 256, 20, 40, 8, 64, 0.08, 65, save_logits=True)
     # sample
+    run_sample("sample_h64", 300, 64, 64, 20, 10, 4, 74, 0.3, 75)
     run_sample("sample_tiny", 200, 32, 32, 20, 20, 8, 71, 0.3, 72)
     run_sample("sample_eq_batch", 5000, 32, 32, 20, 64, 64, 0, 1.0, 73)
     # discriminator alone
