@@ -157,6 +157,27 @@ int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L,
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * CNN discriminator scorer for rollout completions.
+ * Same result as tg_dis_score(completions viewed as [R*L*B, L]) -- the
+ * dis.forward(samples) calls inside ROLLOUT.get_reward's loop
+ * (utils/rollout.py:146-148) -- but exploits what rollout_mc_search guarantees
+ * (utils/rollout.py:42): completions[i, g-1, b, :g] == sentences[b, :g].  Conv
+ * windows that lie inside that shared prefix are evaluated once per sentence
+ * (a running max over time per filter) instead of once per completion; max
+ * pooling is order-independent, so the result is bit-identical.
+ *   sentences        [B,L]        int64
+ *   completions      [R,L,B,L]    int64 (tg_gen_rollout's output layout)
+ *   dropout_uniforms [R*L*B, F]   or NULL
+ *   reward_out       [R*L, B]     raw reward rows (row i*L + g-1)
+ *   workspace        tg_dis_score_rollout_workspace_bytes(w,B,L,R) bytes. */
+size_t tg_dis_score_rollout_workspace_bytes(const TgDisWeights* w, int B, int L, int R);
+int tg_dis_score_rollout(const TgDisWeights* w, const int64_t* sentences,
+                         const int64_t* completions, int B, int L, int R,
+                         int col, float dropout_p,
+                         const float* dropout_uniforms, float* reward_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Reward reshape + mean.
  * Replaces torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153):
  * a reinterpretation of the flat [R*L, B] buffer, not a permute:
@@ -175,6 +196,7 @@ int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
 #define TG_KERNEL_DIS_HIGHWAY 3   /* k_dis_highway                                */
 #define TG_KERNEL_DIS_FINAL 4     /* k_dis_final                                  */
 #define TG_KERNEL_REDUCE 5        /* k_reward_reduce                              */
+#define TG_KERNEL_DIS_PREFIX 6    /* k_dis_conv<store-all> + k_dis_prefix_scan    */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

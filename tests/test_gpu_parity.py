@@ -198,6 +198,25 @@ def test_get_reward(name):
     np.testing.assert_allclose(red, c["raw"].reshape(B, L, R).mean(-1), atol=1e-6, rtol=0)
 
 
+@pytest.mark.parametrize("name", ["reward_senti_k2", "reward_tiny_dropout", "reward_len51", "reward_c2_r1"])
+def test_prefix_reuse_scorer_is_bit_identical(name):
+    """tg_dis_score_rollout (conv windows inside the shared prefix evaluated once per sentence) against the plain
+    scorer on the same completions: identical bits, including B not a multiple of the workgroup's sequence count."""
+    c = _cases.load(name)
+    dis = _dis(c)
+    sent, u, du = _cases.reward_inputs(c)
+    R, L, B = int(c["R"]), int(c["L"]), int(c["B"])
+    comp = _t(c["completions"].astype(np.int64))
+    p = float(c["dropout_p"])
+    dut = None if du is None else _t(du.reshape(R * L * B, -1))
+    plain = tg.ops.dis_score(dis, comp.view(R * L * B, L), col=int(c["current_k"]) + 1, dropout_p=p,
+                             dropout_uniforms=dut)["reward"].view(R * L, B)
+    fast = tg.ops.dis_score_rollout(dis, _t(sent), comp, col=int(c["current_k"]) + 1, dropout_p=p,
+                                    dropout_uniforms=dut)
+    assert torch.equal(plain, fast)
+    np.testing.assert_allclose(fast.cpu().numpy(), c["raw"], atol=1e-4, rtol=0)
+
+
 def test_get_reward_c1_full_vs_oracle():
     """BASELINE config 1 at full size (V5000 L20 E=H=32 B64 R16): 20 480 completions against the
     oracle; step-wise token parity, and rewards on rows whose completions agree."""

@@ -27,6 +27,44 @@ __device__ __forceinline__ float tg_expf(float x) {
     return (x < -104.0f) ? 0.0f : v;  // also maps -inf (masked logits) to exactly 0
 }
 
+// Same for x <= 0 with no range guards (7 VALU per call incl. the caller's subtract): the inner
+// softmax loop.  Very negative x (down to TG_NEG_BIG - anything finite) gives exactly 0, no NaN.
+#define TG_NEG_BIG (-1.0e30f)
+__device__ __forceinline__ float tg_expf_neg(float x) {
+    const float L2E_HI = 1.44269502162933349609375f;
+    const float L2E_LO = 1.92596299112661746e-8f;
+    const float hi = x * L2E_HI;
+    float lo = __builtin_fmaf(x, L2E_HI, -hi);
+    lo = __builtin_fmaf(x, L2E_LO, lo);
+    const float r = __builtin_amdgcn_exp2f(hi);
+    return __builtin_fmaf(r, lo * 0.693147182464599609375f, r);
+}
+
+// 16 of them at once, staged so that the element chains are independent (ILP) and adjacent pairs map
+// onto v_pk_mul_f32 / v_pk_fma_f32: out[r] = exp(x[r] - m), x[r] <= m.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void tg_exp16_neg(const f32x16& x, float m, float (&out)[16]) {
+    const f32x2 L2E_HI = {1.44269502162933349609375f, 1.44269502162933349609375f};
+    const f32x2 L2E_LO = {1.92596299112661746e-8f, 1.92596299112661746e-8f};
+    const f32x2 LN2 = {0.693147182464599609375f, 0.693147182464599609375f};
+    const f32x2 m2 = {m, m};
+    f32x2 d[8], hi[8], lo[8], e[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { const f32x2 v = {x[2 * i], x[2 * i + 1]}; d[i] = v - m2; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) hi[i] = d[i] * L2E_HI;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = __builtin_elementwise_fma(d[i], L2E_HI, -hi[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) lo[i] = __builtin_elementwise_fma(d[i], L2E_LO, lo[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { e[i].x = __builtin_amdgcn_exp2f(hi[i].x); e[i].y = __builtin_amdgcn_exp2f(hi[i].y); }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) e[i] = __builtin_elementwise_fma(e[i], lo[i] * LN2, e[i]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { out[2 * i] = e[i].x; out[2 * i + 1] = e[i].y; }
+}
+
 __device__ __forceinline__ float tg_sigmoid(float x) { return 1.0f / (1.0f + tg_expf(-x)); }
 
 __device__ __forceinline__ float tg_tanh(float x) {

@@ -25,10 +25,18 @@ struct ConvItem {
     uint8_t mt;  // 32-filter tile of that width
 };
 
+// k_dis_conv modes
+constexpr int kConvPlain = 0;   // any [N,L] sequences: all windows, pooled out
+constexpr int kConvStoreAll = 1;// base sentences: every window's conv+bias value out (cv [N,L,F])
+constexpr int kConvPrefix = 2;  // rollout completions [R,L,B,L]: sequence n = (i, g-1, b) shares its first g tokens
+                                // with sentence b, so windows inside the prefix come from the running-max table
+
 struct ConvArgs {
     TgDisWeights w;
     const int64_t* seqs;  // [N,L]
     float* pooled;        // [N,F]
+    float* cv;            // StoreAll: [N,L,F] out; Prefix: running max over time of the sentences' windows, in
+    int B;                // Prefix: sentences per (i, g) block
     int N, L;
     int S, log2S;         // sequences per workgroup (power of two <= 32), TT = 32 / S
     int n_items;
@@ -36,6 +44,7 @@ struct ConvArgs {
     ConvItem items[kMaxItems]; // sorted by cost, heaviest first
 };
 
+template <int MODE>
 __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ebuf = reinterpret_cast<float*>(smem);  // [L][S][68]
@@ -64,6 +73,17 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 
     const int s = n & (S - 1);   // this lane's sequence within the workgroup
     const int tsub = n >> log2S; // and its time sub-position within a tile
+    // Prefix mode: given_num of this lane's sequence, and the smallest one in the workgroup
+    int g_lane = 0, g_min = 0, b_lane = 0;
+    if (MODE == kConvPrefix) {
+        const int seq = tg_min(seq0 + s, a.N - 1);
+        g_lane = (seq / a.B) % L + 1;
+        b_lane = seq % a.B;
+        g_min = g_lane;
+#pragma unroll
+        for (int off = 1; off < 32; off <<= 1) g_min = tg_min(g_min, __shfl_xor(g_min, off, 64));
+        g_min = __builtin_amdgcn_readfirstlane(g_min);
+    }
 
     for (;;) {
         int item = 0;
@@ -81,7 +101,9 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) runmax[r] = TG_NEG_INF;
 
-        for (int nb0 = 0; nb0 < ntile; nb0 += 4) {
+        // windows t <= g - f lie inside the shared prefix: start at the first tile with a fresh window
+        const int nb_start = (MODE == kConvPrefix) ? (tg_max(0, g_min - f + 1) >> (5 - log2S)) : 0;
+        for (int nb0 = nb_start; nb0 < ntile; nb0 += 4) {
             const int nbc = tg_min(4, ntile - nb0);
             f32x16 acc[4];
             int boff[4];
@@ -112,11 +134,27 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
             }
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const bool ok = (nt < nbc) && ((nb0 + nt) * TT + tsub < T);
+                const int tw = (nb0 + nt) * TT + tsub;
+                const bool ok = (nt < nbc) && (tw < T);
+                if (MODE == kConvStoreAll) {
+                    if (ok && seq0 + s < a.N) {
+                        float* po = a.cv + ((size_t)(seq0 + s) * L + tw) * a.w.F + a.foff[k];
+                        const float* pb = a.w.conv_b[k];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], ok ? acc[nt][r] : TG_NEG_INF);
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int m0 = mt * 32 + 8 * rq + 4 * hh;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (m0 + e < nk) po[m0 + e] = acc[nt][4 * rq + e] + pb[m0 + e];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], ok ? acc[nt][r] : TG_NEG_INF);
+                }
             }
         }
+        if (MODE == kConvStoreAll) continue;
         // combine the TT time sub-positions of a sequence (lanes n, n+S, n+2S, ...)
         for (int off = S; off < 32; off <<= 1) {
 #pragma unroll
@@ -126,6 +164,9 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         if (tsub == 0 && seq0 + s < a.N) {
             float* po = a.pooled + (size_t)(seq0 + s) * a.w.F + a.foff[k];
             const float* pb = a.w.conv_b[k];
+            // Prefix mode: max over the windows t <= g - f (bias included) of the base sentence
+            const float* pm = (MODE == kConvPrefix && g_lane >= f)
+                                  ? a.cv + ((size_t)b_lane * L + (g_lane - f)) * a.w.F + a.foff[k] : nullptr;
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
                 const int m0 = mt * 32 + 8 * rq + 4 * hh;
@@ -133,14 +174,37 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
+                    if (pm) {
+                        const f32x4 pv = *reinterpret_cast<const f32x4*>(pm + m0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(o[e], pv[e]);
+                    }
                     *reinterpret_cast<f32x4*>(po + m0) = o;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        if (m0 + e < nk) po[m0 + e] = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
+                        if (m0 + e < nk) {
+                            float o = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
+                            if (pm) o = __builtin_fmaxf(o, pm[m0 + e]);
+                            po[m0 + e] = o;
+                        }
                 }
             }
         }
+    }
+}
+
+// Running max over time of the sentences' window values: cv[b][t][f] <- max_{t' <= t} cv[b][t'][f]
+// (entries with t >= L - f_k + 1 of a width are never read).
+__global__ __launch_bounds__(256) void k_dis_prefix_scan(float* cv, int B, int L, int F) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= B * F) return;
+    const int b = idx / F, f = idx - b * F;
+    float* p = cv + (size_t)b * L * F + f;
+    float m = TG_NEG_INF;
+    for (int t = 0; t < L; ++t) {
+        m = __builtin_fmaxf(m, p[(size_t)t * F]);
+        p[(size_t)t * F] = m;
     }
 }
 
@@ -380,46 +444,10 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 }  // namespace
 
-extern "C" size_t tg_dis_workspace_bytes(const TgDisWeights* w, int N, int L) {
-    (void)L;
-    if (!w || N < 1) return 0;
-    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
-    return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut);
-}
+namespace {
 
-extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L, int col, float dropout_p,
-                            const float* dropout_uniforms, float* reward_out, float* logits_out, float* feature_out,
-                            void* workspace, size_t workspace_bytes, void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
-    if (N < 0 || L < 1 || !seqs) {
-        tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
-        return TG_ERR_ARG;
-    }
-    int rc = check_dis(w, L);
-    if (rc) return rc;
-    if (reward_out && (col < 0 || col >= w->n_out)) {
-        tg_set_error("tg_dis_score: softmax column %d outside [0,%d)", col, w->n_out);
-        return TG_ERR_ARG;
-    }
-    if (dropout_p < 0.f || dropout_p >= 1.f) {
-        tg_set_error("tg_dis_score: dropout p=%f outside [0,1)", dropout_p);
-        return TG_ERR_ARG;
-    }
-    if (N == 0) return TG_OK;
-    if (!workspace || workspace_bytes < tg_dis_workspace_bytes(w, N, L)) {
-        tg_set_error("tg_dis_score: workspace too small (%zu < %zu)", workspace_bytes, tg_dis_workspace_bytes(w, N, L));
-        return TG_ERR_WORKSPACE;
-    }
-    float* pooled = (float*)workspace;
-    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
-    float* partial = (float*)((char*)workspace + align256(sizeof(float) * (size_t)N * w->F));
-
-    // ---- conv
-    ConvArgs ca = {};
+int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int L, size_t* smem) {
     ca.w = *w;
-    ca.seqs = seqs;
-    ca.pooled = pooled;
-    ca.N = N;
     ca.L = L;
     int S = 32, log2S = 5;
     while (S > 1 && (size_t)L * S * kERow * sizeof(float) + 64 > 144 * 1024) { S >>= 1; --log2S; }
@@ -451,10 +479,15 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
     }
     for (int i = 0; i < ni; ++i) { ca.items[i].k = (uint8_t)tmp[i].k; ca.items[i].mt = (uint8_t)tmp[i].mt; }
     ca.n_items = ni;
-    const size_t sm = (size_t)L * S * kERow * sizeof(float) + 64;
+    *smem = (size_t)L * S * kERow * sizeof(float) + 64;
+    return TG_OK;
+}
+
+template <int MODE>
+int launch_conv(const ConvArgs& ca, size_t sm, hipStream_t stream) {
     static thread_local size_t conv_set = 0;
     if (sm > 48 * 1024 && sm > conv_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_conv),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_conv<MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             tg_set_error("hipFuncSetAttribute(k_dis_conv): %s", hipGetErrorString(e));
@@ -462,9 +495,75 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
         }
         conv_set = sm;
     }
-    tg_prof_begin(TG_KERNEL_DIS_CONV, stream);
-    hipLaunchKernelGGL(k_dis_conv, dim3((N + S - 1) / S), dim3(kConvThreads), sm, stream, ca);
+    tg_prof_begin(MODE == kConvStoreAll ? TG_KERNEL_DIS_PREFIX : TG_KERNEL_DIS_CONV, stream);
+    hipLaunchKernelGGL(k_dis_conv<MODE>, dim3((ca.N + ca.S - 1) / ca.S), dim3(kConvThreads), sm, stream, ca);
     tg_prof_end(stream);
+    return TG_OK;
+}
+
+size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
+    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
+    return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut) +
+           align256(sizeof(float) * (size_t)B_prefix * L * w->F);
+}
+
+// sentences == nullptr: plain scoring of N arbitrary sequences.
+// sentences != nullptr: seqs is [R,L,B,L] rollout completions (N = R*L*B), prefix reuse.
+int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const int64_t* sentences, int B, int col,
+               float dropout_p, const float* dropout_uniforms, float* reward_out, float* logits_out,
+               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    if (N < 0 || L < 1 || !seqs) {
+        tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
+        return TG_ERR_ARG;
+    }
+    int rc = check_dis(w, L);
+    if (rc) return rc;
+    if (reward_out && (col < 0 || col >= w->n_out)) {
+        tg_set_error("tg_dis_score: softmax column %d outside [0,%d)", col, w->n_out);
+        return TG_ERR_ARG;
+    }
+    if (dropout_p < 0.f || dropout_p >= 1.f) {
+        tg_set_error("tg_dis_score: dropout p=%f outside [0,1)", dropout_p);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    const size_t need = ws_bytes(w, N, L, sentences ? B : 0);
+    if (!workspace || workspace_bytes < need) {
+        tg_set_error("tg_dis_score: workspace too small (%zu < %zu)", workspace_bytes, need);
+        return TG_ERR_WORKSPACE;
+    }
+    float* pooled = (float*)workspace;
+    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
+    float* partial = (float*)((char*)workspace + align256(sizeof(float) * (size_t)N * w->F));
+    float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut));
+
+    // ---- conv
+    ConvArgs ca = {};
+    size_t sm = 0;
+    rc = prepare_conv(ca, w, L, &sm);
+    if (rc) return rc;
+    if (sentences) {
+        // (1) every window of the B base sentences, (2) running max over time, (3) completions: fresh windows only
+        ca.seqs = sentences;
+        ca.N = B;
+        ca.cv = cv;
+        rc = launch_conv<kConvStoreAll>(ca, sm, stream);
+        if (rc) return rc;
+        tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+        hipLaunchKernelGGL(k_dis_prefix_scan, dim3((B * w->F + 255) / 256), dim3(256), 0, stream, cv, B, L, w->F);
+        tg_prof_end(stream);
+        ca.seqs = seqs;
+        ca.pooled = pooled;
+        ca.N = N;
+        ca.B = B;
+        rc = launch_conv<kConvPrefix>(ca, sm, stream);
+    } else {
+        ca.seqs = seqs;
+        ca.pooled = pooled;
+        ca.N = N;
+        rc = launch_conv<kConvPlain>(ca, sm, stream);
+    }
+    if (rc) return rc;
 
     // ---- highway + gate + dropout + partial logits
     HwArgs ha = {};
@@ -501,4 +600,34 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
         return TG_ERR_LAUNCH;
     }
     return TG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t tg_dis_workspace_bytes(const TgDisWeights* w, int N, int L) {
+    if (!w || N < 1) return 0;
+    return ws_bytes(w, N, L, 0);
+}
+
+extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L, int col, float dropout_p,
+                            const float* dropout_uniforms, float* reward_out, float* logits_out, float* feature_out,
+                            void* workspace, size_t workspace_bytes, void* stream) {
+    return score_impl(w, seqs, N, L, nullptr, 0, col, dropout_p, dropout_uniforms, reward_out, logits_out,
+                      feature_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+extern "C" size_t tg_dis_score_rollout_workspace_bytes(const TgDisWeights* w, int B, int L, int R) {
+    if (!w || B < 1 || L < 1 || R < 1) return 0;
+    return ws_bytes(w, R * L * B, L, B);
+}
+
+extern "C" int tg_dis_score_rollout(const TgDisWeights* w, const int64_t* sentences, const int64_t* completions,
+                                    int B, int L, int R, int col, float dropout_p, const float* dropout_uniforms,
+                                    float* reward_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!sentences || B < 1 || R < 0 || (long)R * L * B > 0x7fffffffL) {
+        tg_set_error("tg_dis_score_rollout: bad arguments (B=%d L=%d R=%d)", B, L, R);
+        return TG_ERR_ARG;
+    }
+    return score_impl(w, completions, R * L * B, L, sentences, B, col, dropout_p, dropout_uniforms, reward_out,
+                      nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
 }

@@ -21,6 +21,10 @@
 //   !REG (H in {32,64,128,256,512}, E any multiple of 32 -- the scaled config): h and the
 //        step's embedded inputs live in LDS ([32][H+4], [32][E+4]), gate weights stream from L2;
 //        each wave owns H/32 gate tiles (its c state: H/8 VGPRs).
+#include <stdlib.h>
+
+#include <type_traits>
+
 #include "tg_common.h"
 
 namespace {
@@ -58,15 +62,16 @@ struct GenArgs {
     float* logits_out;         // [N,L,V] or null
     float* states_out;         // [L+1,N,2,H] or null
     int need_proj;
+    long long* stamps;  // diagnostic (TG_STAMPS env = device pointer): per-workgroup s_memtime sums [grid][4]
 };
 
 
 // One row of W_out (H floats) dotted with h in the MFMA's own k order (per 32-wide chunk the
-// k pairs (j, 16+j), j = 0..15, starting from the bias), so that a recomputed logit reproduces
+// k pairs (j, 16+j), j = 0..15, then the bias), so that a recomputed logit reproduces
 // the MFMA result.
 template <int HT>
 __device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, const float* hrow, float bias) {
-    float acc = bias;
+    float acc = 0.f;
 #pragma unroll 2
     for (int c = 0; c < HT; ++c) {
         const f32x4* w4 = reinterpret_cast<const f32x4*>(wrow + 32 * c);
@@ -79,7 +84,7 @@ __device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, 
             acc = __builtin_fmaf(wh[j >> 2][j & 3], hrow[32 * c + 16 + j], acc);
         }
     }
-    return acc;
+    return acc + bias;  // the bias enters last, as one more k step (a = b_out[v], b = 1)
 }
 
 // 16 consecutive floats (64 B, 16-B aligned) -> registers
@@ -96,7 +101,7 @@ __device__ __forceinline__ void load16(const float* p, float (&dst)[16]) {
 __device__ __forceinline__ int clamp_tok(int64_t t, int V) { return tg_min(tg_max((int)t, 0), V - 1); }
 
 template <bool SAMPLE, int HT, bool REG>
-__global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gen(const GenArgs a) {
     constexpr int kH = 32 * HT;
     constexpr int kHStride = kH + 4;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
     static_assert(!REG || HT == 1, "register-resident operands need H = 32");
@@ -219,7 +224,9 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
     const int a_r = (am & 3) + 4 * (am >> 3);
     const int last_span = (V - 1) / Ls;
 
+    long long st_cell = 0, st_proj = 0, st_draw = 0, st_n = 0;
     for (int t = t0; t < L; ++t) {
+        const long long c0 = clock64();
         // ============================================================== LSTM cell
         if constexpr (REG) {
             float xb[16];
@@ -316,72 +323,169 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
             continue;
         }
 
+        const long long c1 = clock64();
         // ============================================================== projection + online softmax
-        float m_run = TG_NEG_INF;
-        float c_grp = 0.f;   // SAMPLE: current group's sum at scale m_run; TF: running sum of the span
+        float m_run = TG_NEG_BIG;  // finite sentinel: exp(TG_NEG_BIG - m) is exactly 0, never NaN
+        float c_grp = 0.f;         // SAMPLE: current group's sum at scale m_run; TF: running sum of the span
         const int sp_lo = sp * Ls;
         {
-            float a_cur[16], a_nxt[16] = {};
-            if constexpr (REG) load16(a.w.w_out + (size_t)tg_min(a_sp * Ls + a_r, V - 1) * kH + 16 * hh, a_cur);
-            for (int q = 0; q < NT; ++q) {
+            // one 32x32 tile: 16 consecutive vocab entries of this lane's span, all 32 rows
+            auto tile = [&](int q, const float (&areg)[16], auto full_tag) {
+                constexpr bool full = decltype(full_tag)::value;  // every lane's 16 entries are < V
                 const int vb = sp_lo + 16 * q;
                 f32x16 acc;
-                if (vb + 16 <= V) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                if constexpr (REG) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) acc = TG_MFMA32(areg[j], hb[j], acc);
+                } else {
+                    const float* wrow = a.w.w_out + (size_t)tg_min(a_sp * Ls + 16 * q + a_r, V - 1) * kH + 16 * hh;
+                    const float* hrow = hbuf + n * kHStride + 16 * hh;
+                    float av[16], bv[16];
+                    for (int c = 0; c < HT; ++c) {
+                        load16(wrow + 32 * c, av);
+                        load16(hrow + 32 * c, bv);
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(av[j], bv[j], acc);
+                    }
+                }
+                if (full) {
                     const f32x4* pb = reinterpret_cast<const f32x4*>(a.w.b_out + vb);
 #pragma unroll
                     for (int qq = 0; qq < 4; ++qq) {
                         const f32x4 bv = pb[qq];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) acc[4 * qq + e] = bv[e];
+                        for (int e = 0; e < 4; ++e) acc[4 * qq + e] += bv[e];
                     }
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = a.w.b_out[tg_min(vb + r, V - 1)];
+                    for (int r = 0; r < 16; ++r) acc[r] += a.w.b_out[tg_min(vb + r, V - 1)];
                 }
-                if constexpr (REG) {
-                    if (q + 1 < NT)
-                        load16(a.w.w_out + (size_t)tg_min(a_sp * Ls + 16 * (q + 1) + a_r, V - 1) * kH + 16 * hh, a_nxt);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) acc = TG_MFMA32(a_cur[j], hb[j], acc);
-#pragma unroll
-                    for (int j = 0; j < 16; ++j) a_cur[j] = a_nxt[j];
-                } else {
-                    const float* wrow = a.w.w_out + (size_t)tg_min(a_sp * Ls + 16 * q + a_r, V - 1) * kH + 16 * hh;
-                    const float* hrow = hbuf + n * kHStride + 16 * hh;
-                    for (int c = 0; c < HT; ++c) {
-                        load16(wrow + 32 * c, a_cur);
-                        load16(hrow + 32 * c, a_nxt);
-#pragma unroll
-                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(a_cur[j], a_nxt[j], acc);
-                    }
-                }
-                const int nvalid = tg_max(0, tg_min(16, V - vb));
                 if (!SAMPLE && a.logits_out && valid) {
                     float* lo = a.logits_out + (tf_row * L + t) * (size_t)V + vb;
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        if (r < nvalid) lo[r] = acc[r];
+                        if (vb + r < V) lo[r] = acc[r];
                 }
-                float tmax = TG_NEG_INF;
+                if (!full) {  // vocabulary tail (last span only): masked entries weigh exactly 0
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    acc[r] = (r < nvalid) ? acc[r] : TG_NEG_INF;
-                    tmax = __builtin_fmaxf(tmax, acc[r]);
+                    for (int r = 0; r < 16; ++r) acc[r] = (vb + r < V) ? acc[r] : TG_NEG_BIG;
                 }
+                float tmax = acc[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) tmax = __builtin_fmaxf(tmax, acc[r]);
                 const float m_new = __builtin_fmaxf(m_run, tmax);
-                const float m_safe = (m_new == TG_NEG_INF) ? 0.f : m_new;
                 const bool grp_start = SAMPLE && (q % GK == 0);
-                // rescale what was accumulated at the old max (exp(-inf) = 0 on the first tile)
-                c_grp = grp_start ? 0.f : c_grp * tg_expf(m_run - m_safe);
+                // rescale what was accumulated at the old max
+                c_grp = grp_start ? 0.f : c_grp * tg_expf_neg(m_run - m_new);
                 float ts = 0.f;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) ts += tg_expf(acc[r] - m_safe);
+                for (int r = 0; r < 16; ++r) ts += tg_expf_neg(acc[r] - m_new);
                 c_grp += ts;
                 m_run = m_new;
                 if (SAMPLE && ((q % GK == GK - 1) || q == NT - 1))
                     rec[((q / GK) * kNSpan + sp) * kRows + n] = make_float2(m_run, c_grp);
+            };
+            // wave-uniform choice: the odd span of this wave reaches the vocabulary's end first
+            auto tile_any = [&](int q, const float (&areg)[16]) {
+                if ((2 * w + 1) * Ls + 16 * q + 16 <= V) tile(q, areg, std::true_type{});
+                else tile(q, areg, std::false_type{});
+            };
+            int q_done = 0;
+            if constexpr (REG) {
+                if (SAMPLE || !a.logits_out) {
+                    // Software-pipelined loop over all tiles: branch-free body, the MFMAs of tile q+1 are issued
+                    // ahead of tile q's softmax VALU work so that one wave keeps both pipes busy.  Two register
+                    // sets for A and for the accumulator.  Entries past the vocabulary's end are masked through
+                    // the bias operand (TG_NEG_BIG -> weight exactly 0), so the tail needs no separate path.
+                    const int nfull = NT;
+                    const int gk_mask = GK - 1, gk_shift = __builtin_ctz(GK);
+                    // A fragment of a tile: 16 floats of W_out[v] plus, as a 17th k step, the bias of v on the
+                    // k = 0 lanes (against b = 1): one dword per lane instead of a 64-B broadcast bias read.
+                    struct AFrag { float w[16]; float bias; };
+                    const float bone = hh ? 0.f : 1.f;
+                    auto load_a = [&](int q, AFrag& dst) {
+                        const int v = a_sp * Ls + 16 * q + a_r;
+                        load16(a.w.w_out + (size_t)tg_min(v, V - 1) * kH + 16 * hh, dst.w);
+                        dst.bias = hh ? 0.f : (v < V ? a.w.b_out[v] : TG_NEG_BIG);
+                    };
+                    auto mfma_tile = [&](int q, const AFrag& af) {
+                        f32x16 acc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(af.w[j], hb[j], acc);
+                        acc = TG_MFMA32(af.bias, bone, acc);
+                        return acc;
+                    };
+                    auto softmax_tile = [&](const f32x16& acc, int q) {
+                        float tmax = acc[0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) tmax = __builtin_fmaxf(tmax, acc[r]);
+                        const float m_new = __builtin_fmaxf(m_run, tmax);
+                        // branch-free group restart (a select on the scalar condition would split the block
+                        // and serialise the MFMA chain ahead of this VALU work)
+                        const float keep = (SAMPLE && (q & gk_mask) == 0) ? 0.f : 1.f;
+                        c_grp = c_grp * tg_expf_neg(m_run - m_new) * keep;
+                        float ev[16];
+                        tg_exp16_neg(acc, m_new, ev);
+                        float ts = 0.f;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ts += ev[r];  // canonical order: sequential
+                        c_grp += ts;
+                        m_run = m_new;
+                        // stored after every tile: the group's last tile leaves the final value
+                        if (SAMPLE) rec[((q >> gk_shift) * kNSpan + sp) * kRows + n] = make_float2(m_run, c_grp);
+                    };
+                    if (nfull > 0) {
+                        AFrag a0, a1;
+                        f32x16 acc0, acc1;
+                        load_a(0, a0);
+                        if (nfull > 1) load_a(1, a1);
+                        acc0 = mfma_tile(0, a0);
+                        int q = 0;
+                        // ask the scheduler for 1 MFMA : 10 VALU in program order (the in-order wave otherwise
+                        // parks on the dependent MFMA chain with the softmax work queued behind it)
+                        auto interleave = [&]() {
+#pragma unroll
+                            for (int i = 0; i < 17; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // VALU
+                            }
+                        };
+                        for (; q + 2 < nfull; q += 2) {
+                            load_a(q + 2, a0);
+                            acc1 = mfma_tile(q + 1, a1);
+                            softmax_tile(acc0, q);
+                            interleave();
+                            if (q + 3 < nfull) load_a(q + 3, a1);
+                            acc0 = mfma_tile(q + 2, a0);
+                            softmax_tile(acc1, q + 1);
+                            interleave();
+                        }
+                        // q is even here, acc0 holds tile q; one or two tiles remain
+                        if (q + 1 < nfull) {
+                            acc1 = mfma_tile(q + 1, a1);
+                            softmax_tile(acc0, q);
+                            softmax_tile(acc1, q + 1);
+                        } else {
+                            softmax_tile(acc0, q);
+                        }
+                    }
+                    q_done = nfull;
+                }
+                float dummy[16];
+                for (int q = q_done; q < NT; ++q) {
+                    load16(a.w.w_out + (size_t)tg_min(a_sp * Ls + 16 * q + a_r, V - 1) * kH + 16 * hh, dummy);
+                    tile_any(q, dummy);
+                }
+            } else {
+                float dummy[16] = {};
+                for (int q = 0; q < NT; ++q) tile_any(q, dummy);
             }
         }
+        const long long c2 = clock64();
         mbuf[sp * kRows + n] = m_run;
         __syncthreads();
         float M = mbuf[n];
@@ -390,7 +494,7 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
 
         if (!SAMPLE) {
             // ---------------------------------------------------------- teacher forced: lse + picked log-prob
-            sbuf[sp * kRows + n] = (m_run == TG_NEG_INF) ? 0.0 : (double)c_grp * exp((double)(m_run - M));
+            sbuf[sp * kRows + n] = (double)c_grp * exp((double)(m_run - M));  // empty span: c_grp = 0
             __syncthreads();
             if (tid < kRows) {
                 double S = 0.0;
@@ -497,6 +601,12 @@ __global__ __launch_bounds__(kThreads) void k_gen(const GenArgs a) {
         }
         __syncthreads();
         tok = tokbuf[n];
+        const long long c3 = clock64();
+        st_cell += c1 - c0; st_proj += c2 - c1; st_draw += c3 - c2; st_n += 1;
+    }
+    if (SAMPLE && a.stamps && tid == 0) {
+        long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        o[0] = st_cell; o[1] = st_proj; o[2] = st_draw; o[3] = st_n;
     }
 }
 
@@ -542,7 +652,7 @@ int check_weights(const TgGenWeights* w) {
 
 template <bool SAMPLE, int HT, bool REG>
 int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
-    const size_t sm = smem_bytes(a.geo, SAMPLE, a.w.E, a.w.H);
+    size_t sm = smem_bytes(a.geo, SAMPLE, a.w.E, a.w.H);
     if (sm > 160 * 1024) {
         tg_set_error("generator kernel needs %zu bytes of LDS (> 160 KiB) for V=%d E=%d H=%d", sm, a.w.V, a.w.E,
                      a.w.H);
@@ -648,6 +758,7 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
     a.forced = forced;
     a.out = completions;
     a.rollout = 1;
+    { const char* d = getenv("TG_STAMPS"); a.stamps = d ? (long long*)strtoull(d, nullptr, 0) : nullptr; }
     a.B = B;
     a.L = L;
     a.R = R;

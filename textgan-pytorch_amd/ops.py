@@ -93,6 +93,30 @@ def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_rewar
     return {"reward": reward, "logits": logits, "feature": feat}
 
 
+def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout_uniforms=None, reward_out=None,
+                      weights=None):
+    """tg_dis_score_rollout: the scorer over tg_gen_rollout's [R,L,B,L] completions with prefix reuse
+    (windows inside the tokens a completion shares with its sentence are evaluated once per sentence).
+    Returns raw reward rows [R*L, B]."""
+    w, keep = weights if weights is not None else _lib.dis_weights(dis)
+    s, _ = _tokens(sentences, "sentences")
+    comp, _ = _tokens(completions, "completions")
+    R, L, B, L2 = comp.shape
+    if tuple(s.shape) != (B, L) or L2 != L:
+        raise RuntimeError("textgan_hip: completions must be [R,L,B,L] matching sentences [B,L]")
+    dev = s.device
+    reward = reward_out if reward_out is not None else torch.empty(R * L, B, dtype=F32, device=dev)
+    if dropout_p > 0.0 and dropout_uniforms is not None and dropout_uniforms.numel() != R * L * B * w.F:
+        raise RuntimeError("textgan_hip: dropout_uniforms must have R*L*B*F elements")
+    nbytes = _lib.lib().tg_dis_score_rollout_workspace_bytes(C.byref(w), B, L, R)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.lib().tg_dis_score_rollout(
+        C.byref(w), _lib.dev_ptr(s, I64, "sentences"), _lib.dev_ptr(comp, I64, "completions"), B, L, R, int(col),
+        float(dropout_p), _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms"), _lib.dev_ptr(reward, F32, "reward"),
+        _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return reward
+
+
 def reward_reduce(raw, B, L, R):
     """tg_reward_reduce: torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153)."""
     if raw.numel() != R * L * B:

@@ -89,20 +89,22 @@ class ROLLOUT:
                     comp = ops.gen_rollout(self.gen, sentences, Rl, u)
                 p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
                 weights = _lib.dis_weights(dis)
-                seqs = comp.view(Rl * L * B, L)
-                flat = raw_local.view(-1)
                 F = weights[0].F
                 du_all = None
                 if p > 0 and dropout_uniforms is not None:
                     du_all = dropout_uniforms.reshape(R * L * B, F)[plan.i_lo * L * B:plan.i_hi * L * B]
+                # whole rollouts per scorer call, at most dis_chunk sequences each
+                step = max(1, self.dis_chunk // (L * B))
                 with self._timed("dis_score"):
-                    for lo in range(0, seqs.shape[0], self.dis_chunk):
-                        hi = min(seqs.shape[0], lo + self.dis_chunk)
+                    for lo in range(0, Rl, step):
+                        hi = min(Rl, lo + step)
                         du = None
                         if p > 0:
-                            du = du_all[lo:hi].contiguous() if du_all is not None else self._rand((hi - lo, F), dev)
-                        ops.dis_score(dis, seqs[lo:hi], col=current_k + 1, dropout_p=p, dropout_uniforms=du,
-                                      reward_out=flat[lo:hi], weights=weights)
+                            du = (du_all[lo * L * B:hi * L * B].contiguous() if du_all is not None
+                                  else self._rand(((hi - lo) * L * B, F), dev))
+                        ops.dis_score_rollout(dis, sentences, comp[lo:hi], col=current_k + 1, dropout_p=p,
+                                              dropout_uniforms=du, reward_out=raw_local[lo * L:hi * L],
+                                              weights=weights)
             with self._timed("exchange"):
                 raw = tdist.gather_rows(raw_local, plan, L, self.group)
             with self._timed("reduce"):
