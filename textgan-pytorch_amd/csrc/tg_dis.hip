@@ -10,6 +10,8 @@
 //
 // Replaces models/discriminator.py:40-64 and utils/rollout.py:146-148 of the reference.
 // Embedding dim Ed = 64 (config.py:113 of the reference) is compiled in.
+#include <stdlib.h>
+
 #include "tg_common.h"
 
 namespace {
@@ -211,8 +213,10 @@ __global__ __launch_bounds__(256) void k_dis_prefix_scan(float* cv, int B, int L
 // ---------------------------------------------------------------------------------------------
 constexpr int kHwThreads = 256;
 constexpr int kHwTile = 128;   // 128 features x 128 sequences per workgroup
-constexpr int kHwBK = 32;
-constexpr int kHwStride = 36;  // LDS row stride (floats)
+constexpr int kHwBK = 64;
+constexpr int kHwStride = kHwBK + 4;  // LDS row stride (floats): 16-B aligned, odd number of 16-B slots
+constexpr int kHwCh = kHwBK / 4;       // 16-B chunks per tile row
+constexpr int kHwPass = kHwTile * kHwCh / kHwThreads;  // float4 per thread per operand tile
 
 struct HwArgs {
     TgDisWeights w;
@@ -224,15 +228,20 @@ struct HwArgs {
     int N, nchunk, nseqtile;
 };
 
-__device__ __forceinline__ void hw_load_tile(float* dst, const float* src, int row0, int nrows, int k0, int F, int tid) {
-    // 128 rows x 32 floats; rows >= nrows are clamped, k >= F reads as 0
+// One thread's share of a 128-row x 32-float operand tile: 4 float4 (rows r0 + 32*i, 16-B chunk c).
+// Rows >= nrows are clamped, k >= F reads as 0.  Split into an early global->register stage and a late
+// register->LDS stage so the loads of tile k+1 fly under the MFMAs of tile k.
+struct HwStage { f32x4 v[kHwPass]; };
+
+__device__ __forceinline__ void hw_fetch(HwStage& st, const float* src, int row0, int nrows, int k0, int F, int tid) {
     const bool vec = (F & 3) == 0;
-    for (int idx = tid; idx < kHwTile * (kHwBK / 4); idx += kHwThreads) {
-        const int r = idx >> 3, c = idx & 7;
-        const int row = tg_min(row0 + r, nrows - 1);
-        const int k = k0 + 4 * c;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const int c = tid % kHwCh, r0 = tid / kHwCh;  // 256 threads: (256/kHwCh) rows x kHwCh chunks per pass
+    const int k = k0 + 4 * c;
+#pragma unroll
+    for (int i = 0; i < kHwPass; ++i) {
+        const int row = tg_min(row0 + r0 + (kHwThreads / kHwCh) * i, nrows - 1);
         const float* p = src + (size_t)row * F + k;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (vec) {
             if (k < F) v = *reinterpret_cast<const f32x4*>(p);
         } else {
@@ -240,11 +249,18 @@ __device__ __forceinline__ void hw_load_tile(float* dst, const float* src, int r
             for (int e = 0; e < 4; ++e)
                 if (k + e < F) v[e] = p[e];
         }
-        *reinterpret_cast<f32x4*>(dst + r * kHwStride + 4 * c) = v;
+        st.v[i] = v;
     }
 }
 
-__global__ __launch_bounds__(kHwThreads) void k_dis_highway(const HwArgs a) {
+__device__ __forceinline__ void hw_commit(const HwStage& st, float* dst, int tid) {
+    const int c = tid % kHwCh, r0 = tid / kHwCh;
+#pragma unroll
+    for (int i = 0; i < kHwPass; ++i)
+        *reinterpret_cast<f32x4*>(dst + (r0 + (kHwThreads / kHwCh) * i) * kHwStride + 4 * c) = st.v[i];
+}
+
+__global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dis_highway(const HwArgs a) {
     __shared__ __attribute__((aligned(16))) float As[kHwTile * kHwStride];  // hw_w rows (output features)
     __shared__ __attribute__((aligned(16))) float Bs[kHwTile * kHwStride];  // pooled rows (sequences)
     __shared__ float red[2][kHwTile][kMaxOut];                              // cross-wave logit partials
@@ -266,16 +282,25 @@ __global__ __launch_bounds__(kHwThreads) void k_dis_highway(const HwArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    HwStage sa, sb;
+    hw_fetch(sa, a.w.hw_w, f0, F, 0, F, tid);
+    hw_fetch(sb, a.pooled, s0, a.N, 0, F, tid);
     for (int k0 = 0; k0 < F; k0 += kHwBK) {
+        __syncthreads();  // everyone is done reading the previous tile
+        hw_commit(sa, As, tid);
+        hw_commit(sb, Bs, tid);
         __syncthreads();
-        hw_load_tile(As, a.w.hw_w, f0, F, k0, F, tid);
-        hw_load_tile(Bs, a.pooled, s0, a.N, k0, F, tid);
-        __syncthreads();
+        if (k0 + kHwBK < F) {  // next tile's loads fly under this tile's MFMAs
+            hw_fetch(sa, a.w.hw_w, f0, F, k0 + kHwBK, F, tid);
+            hw_fetch(sb, a.pooled, s0, a.N, k0 + kHwBK, F, tid);
+        }
+#pragma unroll
+        for (int kc = 0; kc < kHwBK / 32; ++kc) {
         float af[2][16], bf[2][16];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const float* pa = As + (wm * 64 + i * 32 + n) * kHwStride + 16 * hh;
-            const float* pb = Bs + (wn * 64 + i * 32 + n) * kHwStride + 16 * hh;
+            const float* pa = As + (wm * 64 + i * 32 + n) * kHwStride + 32 * kc + 16 * hh;
+            const float* pb = Bs + (wn * 64 + i * 32 + n) * kHwStride + 32 * kc + 16 * hh;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const f32x4 va = *reinterpret_cast<const f32x4*>(pa + 4 * q);
@@ -290,6 +315,7 @@ __global__ __launch_bounds__(kHwThreads) void k_dis_highway(const HwArgs a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) acc[i][jn] = TG_MFMA32(af[i][j], bf[jn][j], acc[i][jn]);
+        }
     }
 
     // ---- epilogue: gate, dropout, partial feature2out dot (lane = sequence, regs = features)
@@ -446,11 +472,13 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 namespace {
 
-int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int L, size_t* smem) {
+int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem) {
     ca.w = *w;
     ca.L = L;
     int S = 32, log2S = 5;
     while (S > 1 && (size_t)L * S * kERow * sizeof(float) + 64 > 144 * 1024) { S >>= 1; --log2S; }
+    // few sequences (the base sentences of the prefix pass): fewer per workgroup so that the grid fills the chip
+    while (S > 1 && (N + S - 1) / S < 512) { S >>= 1; --log2S; }
     if ((size_t)L * S * kERow * sizeof(float) + 64 > 160 * 1024) {
         tg_set_error("tg_dis_score: sequence length %d too long for the LDS-resident conv kernel", L);
         return TG_ERR_ARG;
@@ -540,7 +568,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     // ---- conv
     ConvArgs ca = {};
     size_t sm = 0;
-    rc = prepare_conv(ca, w, L, &sm);
+    rc = prepare_conv(ca, w, sentences ? B : N, L, &sm);
     if (rc) return rc;
     if (sentences) {
         // (1) every window of the B base sentences, (2) running max over time, (3) completions: fresh windows only
@@ -552,8 +580,11 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
         hipLaunchKernelGGL(k_dis_prefix_scan, dim3((B * w->F + 255) / 256), dim3(256), 0, stream, cv, B, L, w->F);
         tg_prof_end(stream);
+        rc = prepare_conv(ca, w, N, L, &sm);
+        if (rc) return rc;
         ca.seqs = seqs;
         ca.pooled = pooled;
+        ca.cv = cv;
         ca.N = N;
         ca.B = B;
         rc = launch_conv<kConvPrefix>(ca, sm, stream);
