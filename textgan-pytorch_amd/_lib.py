@@ -31,7 +31,7 @@ class DisW(C.Structure):
     _fields_ = [("emb", C.c_void_p), ("conv_w", C.c_void_p * MAX_FILTERS), ("conv_b", C.c_void_p * MAX_FILTERS),
                 ("hw_w", C.c_void_p), ("hw_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
                 ("f", C.c_int32 * MAX_FILTERS), ("n", C.c_int32 * MAX_FILTERS), ("n_filters", C.c_int32),
-                ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("_pad", C.c_int32)]
+                ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("precision", C.c_int32)]
 
 
 _lib = None
@@ -128,10 +128,16 @@ def gen_weights(gen):
     return w, keep
 
 
-def dis_weights(dis):
+PRECISIONS = {"fp32": 0, "split_f16": 1}
+#: conv arithmetic used when a caller does not say: see TG_DIS_* in include/textgan_hip.h
+default_dis_precision = "split_f16"
+
+
+def dis_weights(dis, precision=None):
     """Pack the live parameters of a CNNDiscriminator-shaped module (models/discriminator.py:30-36)."""
     keep = []
     w = DisW()
+    w.precision = PRECISIONS[precision or default_dis_precision]
     d, w.emb = _param(dis.embeddings.weight, "embeddings.weight")
     keep.append(d)
     V, Ed = d.shape

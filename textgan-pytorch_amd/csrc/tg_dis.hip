@@ -43,13 +43,29 @@ struct ConvArgs {
     int S, log2S;         // sequences per workgroup (power of two <= 32), TT = 32 / S
     int n_items;
     int foff[TG_MAX_FILTERS];  // feature offset of each width
+    // split-fp16 path: weights pre-split into scaled (hi, lo) halves, bank k's hi part at w16 + woff[k],
+    // its lo part n_k*f_k*64 halves later; scales = {scale_w, scale_e, 1/(scale_w*scale_e)} on the device
+    const _Float16* w16;
+    const float* scales;
+    int woff[TG_MAX_FILTERS];
     ConvItem items[kMaxItems]; // sorted by cost, heaviest first
 };
 
-template <int MODE>
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+constexpr int kERowH = 2 * kERow;  // LDS halves per embedded token in the split path: [64 hi | 64 lo | 8 pad]
+#define TG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// SPLIT = false: exact fp32 on v_mfma_f32_32x32x2_f32.
+// SPLIT = true:  x = hi + lo with hi = fp16(x*scale), lo = fp16(x*scale - hi) (22 mantissa bits; scale a power of
+//                two that puts the tensor's max near 2^14); w.e ~ w_hi.e_hi + w_hi.e_lo + w_lo.e_hi on
+//                v_mfma_f32_32x32x16_f16 with fp32 accumulation: ~5e-7 relative per product at 3/16 of the
+//                fp32-MFMA cycles.
+template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* ebuf = reinterpret_cast<float*>(smem);  // [L][S][68]
+    float* ebuf = reinterpret_cast<float*>(smem);  // [L][S][68] floats, or [L][S][136] halves (same bytes)
+    _Float16* ebuf_h = reinterpret_cast<_Float16*>(smem);
     const int L = a.L, S = a.S, log2S = a.log2S, TT = 32 >> log2S;
     int* ctr = reinterpret_cast<int*>(ebuf + (size_t)L * S * kERow);
 
@@ -68,7 +84,20 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         int tok = (int)a.seqs[(size_t)seq * L + t];
         tok = tg_min(tg_max(tok, 0), a.w.V - 1);
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tok * kEd + 4 * c);
-        *reinterpret_cast<f32x4*>(ebuf + (size_t)ts * kERow + 4 * c) = v;
+        if (!SPLIT) {
+            *reinterpret_cast<f32x4*>(ebuf + (size_t)ts * kERow + 4 * c) = v;
+        } else {
+            const float sc = a.scales[1];
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[e] * sc;
+                h[e] = (_Float16)x;
+                l[e] = (_Float16)(x - (float)h[e]);
+            }
+            *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + 4 * c) = h;
+            *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + kEd + 4 * c) = l;
+        }
     }
     if (tid == 0) *ctr = 0;
     __syncthreads();
@@ -97,6 +126,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         const int K = f * kEd, T = L - f + 1;
         const int arow = tg_min(mt * 32 + n, nk - 1);
         const float* wp = a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
+        const _Float16* wph = SPLIT ? a.w16 + a.woff[k] + (size_t)arow * K + 8 * hh : nullptr;
+        const size_t wlo_off = (size_t)nk * K;
         const int ntile = (T + TT - 1) >> (5 - log2S);  // ceil(T / TT)
 
         float runmax[16];
@@ -114,8 +145,37 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
                 const int t = tg_min((nb0 + nt) * TT + tsub, T - 1);
-                boff[nt] = (t * S + s) * kERow + 32 * hh;
+                boff[nt] = SPLIT ? (t * S + s) * kERowH + 8 * hh : (t * S + s) * kERow + 32 * hh;
             }
+            if (SPLIT) {
+                for (int tau = 0; tau < f; ++tau) {
+                    f16x8 ah[4], al[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+                        ah[ks] = *reinterpret_cast<const f16x8*>(wph + tau * kEd + 16 * ks);
+                        al[ks] = *reinterpret_cast<const f16x8*>(wph + wlo_off + tau * kEd + 16 * ks);
+                    }
+                    const int toff = tau * S * kERowH;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; ++nt) {
+                            if (nt < nbc) {
+                                const f16x8 bh = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + 16 * ks);
+                                const f16x8 bl = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + kEd + 16 * ks);
+                                acc[nt] = TG_MFMA16(ah[ks], bh, acc[nt]);
+                                acc[nt] = TG_MFMA16(ah[ks], bl, acc[nt]);
+                                acc[nt] = TG_MFMA16(al[ks], bh, acc[nt]);
+                            }
+                        }
+                    }
+                }
+                const float inv = a.scales[2];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[nt][r] *= inv;
+            } else
             for (int tau = 0; tau < f; ++tau) {
                 f32x4 av[8];
                 const f32x4* pa = reinterpret_cast<const f32x4*>(wp + tau * kEd);
@@ -193,6 +253,55 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 }
             }
         }
+    }
+}
+
+// ---- split-fp16 preparation: |max| of a tensor, power-of-two scales, (hi, lo) halves of the conv weights
+__global__ __launch_bounds__(256) void k_absmax(const float* x, size_t n, unsigned* out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);  // |x| as ordered bits (NaN sorts high: scale 1 below)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__global__ void k_make_scales(const unsigned* absmax, float* scales) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float sc[2];
+    for (int i = 0; i < 2; ++i) {
+        const float m = __uint_as_float(absmax[i]);
+        int ex = 0;
+        sc[i] = 1.f;
+        if (m > 0.f && m < __builtin_inff()) {
+            (void)frexpf(m, &ex);          // m < 2^ex
+            sc[i] = ldexpf(1.f, 14 - ex);  // m*scale in [2^13, 2^14)
+        }
+    }
+    scales[0] = sc[0];
+    scales[1] = sc[1];
+    scales[2] = 1.f / (sc[0] * sc[1]);
+}
+
+struct SplitArgs {
+    const float* src[TG_MAX_FILTERS];
+    int woff[TG_MAX_FILTERS];
+    int count[TG_MAX_FILTERS];  // n_k * f_k * 64
+    int n_filters;
+    _Float16* w16;
+    const float* scales;
+};
+
+__global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
+    const int k = blockIdx.y;
+    const float sc = a.scales[0];
+    _Float16* hi = a.w16 + a.woff[k];
+    _Float16* lo = hi + a.count[k];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.count[k]; i += gridDim.x * 256) {
+        const float x = a.src[k][i] * sc;
+        const _Float16 h = (_Float16)x;
+        hi[i] = h;
+        lo[i] = (_Float16)(x - (float)h);
     }
 }
 
@@ -467,6 +576,7 @@ int check_dis(const TgDisWeights* w, int L) {
 }
 
 inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+inline int tg_min_host(int a, int b) { return a < b ? a : b; }
 
 }  // namespace
 
@@ -511,11 +621,11 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
     return TG_OK;
 }
 
-template <int MODE>
-int launch_conv(const ConvArgs& ca, size_t sm, hipStream_t stream) {
+template <int MODE, bool SPLIT>
+int launch_conv_t(const ConvArgs& ca, size_t sm, hipStream_t stream) {
     static thread_local size_t conv_set = 0;
     if (sm > 48 * 1024 && sm > conv_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_conv<MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_conv<MODE, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             tg_set_error("hipFuncSetAttribute(k_dis_conv): %s", hipGetErrorString(e));
@@ -524,15 +634,65 @@ int launch_conv(const ConvArgs& ca, size_t sm, hipStream_t stream) {
         conv_set = sm;
     }
     tg_prof_begin(MODE == kConvStoreAll ? TG_KERNEL_DIS_PREFIX : TG_KERNEL_DIS_CONV, stream);
-    hipLaunchKernelGGL(k_dis_conv<MODE>, dim3((ca.N + ca.S - 1) / ca.S), dim3(kConvThreads), sm, stream, ca);
+    hipLaunchKernelGGL((k_dis_conv<MODE, SPLIT>), dim3((ca.N + ca.S - 1) / ca.S), dim3(kConvThreads), sm, stream, ca);
     tg_prof_end(stream);
     return TG_OK;
+}
+
+template <int MODE>
+int launch_conv(const ConvArgs& ca, size_t sm, hipStream_t stream) {
+    return ca.w16 ? launch_conv_t<MODE, true>(ca, sm, stream) : launch_conv_t<MODE, false>(ca, sm, stream);
+}
+
+size_t conv_weight_count(const TgDisWeights* w) {
+    size_t n = 0;
+    for (int k = 0; k < w->n_filters; ++k) n += (size_t)w->n[k] * w->f[k] * kEd;
+    return n;
 }
 
 size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
     const int nchunk = (w->F + kHwTile - 1) / kHwTile;
     return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut) +
-           align256(sizeof(float) * (size_t)B_prefix * L * w->F);
+           align256(sizeof(float) * (size_t)B_prefix * L * w->F) +
+           align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256;
+}
+
+// Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
+// of all conv banks, the two power-of-two scales, and the (hi, lo) halves of the conv weights.
+int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, hipStream_t stream) {
+    unsigned* absmax = (unsigned*)scal;          // [0] conv weights, [1] embedding table
+    float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e)}
+    if (hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
+        tg_set_error("hipMemsetAsync failed");
+        return TG_ERR_LAUNCH;
+    }
+    tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+    SplitArgs sa = {};
+    int off = 0, maxcount = 0;
+    for (int k = 0; k < w->n_filters; ++k) {
+        const int cnt = w->n[k] * w->f[k] * kEd;
+        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((cnt + 255) / 256, 256)), dim3(256), 0, stream, w->conv_w[k],
+                           (size_t)cnt, absmax);
+        sa.src[k] = w->conv_w[k];
+        sa.woff[k] = off;
+        sa.count[k] = cnt;
+        ca.woff[k] = off;
+        off += 2 * cnt;
+        maxcount = cnt > maxcount ? cnt : maxcount;
+    }
+    const size_t ne = (size_t)w->V * kEd;
+    hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 512)), dim3(256), 0, stream, w->emb, ne,
+                       absmax + 1);
+    hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
+    sa.n_filters = w->n_filters;
+    sa.w16 = w16;
+    sa.scales = scales;
+    hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters), dim3(256), 0,
+                       stream, sa);
+    tg_prof_end(stream);
+    ca.w16 = w16;
+    ca.scales = scales;
+    return TG_OK;
 }
 
 // sentences == nullptr: plain scoring of N arbitrary sequences.
@@ -564,12 +724,21 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     const int nchunk = (w->F + kHwTile - 1) / kHwTile;
     float* partial = (float*)((char*)workspace + align256(sizeof(float) * (size_t)N * w->F));
     float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut));
+    _Float16* w16 = (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
+    void* scal = (char*)w16 + align256(2 * sizeof(_Float16) * conv_weight_count(w));
 
     // ---- conv
     ConvArgs ca = {};
     size_t sm = 0;
     rc = prepare_conv(ca, w, sentences ? B : N, L, &sm);
     if (rc) return rc;
+    if (w->precision == TG_DIS_SPLIT_F16) {
+        rc = prepare_split(ca, w, w16, scal, stream);
+        if (rc) return rc;
+    } else if (w->precision != TG_DIS_FP32) {
+        tg_set_error("tg_dis_score: unknown precision %d", w->precision);
+        return TG_ERR_ARG;
+    }
     if (sentences) {
         // (1) every window of the B base sentences, (2) running max over time, (3) completions: fresh windows only
         ca.seqs = sentences;

@@ -72,10 +72,10 @@ def gen_sample(gen, N, L, start_letter, uniforms, forced=None):
 
 
 def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_reward=True, want_logits=False,
-              want_feature=False, reward_out=None, weights=None):
+              want_feature=False, reward_out=None, weights=None, precision=None):
     """tg_dis_score: CNNDiscriminator.forward (models/discriminator.py:40-64) + softmax column
     (utils/rollout.py:146-148).  seqs [N,L]; returns dict(reward [N], logits [N,n_out], feature [N,F])."""
-    w, keep = weights if weights is not None else _lib.dis_weights(dis)
+    w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
     s, _ = _tokens(seqs, "seqs")
     N, L = s.shape
     dev = s.device
@@ -94,11 +94,11 @@ def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_rewar
 
 
 def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout_uniforms=None, reward_out=None,
-                      weights=None):
+                      weights=None, precision=None):
     """tg_dis_score_rollout: the scorer over tg_gen_rollout's [R,L,B,L] completions with prefix reuse
     (windows inside the tokens a completion shares with its sentence are evaluated once per sentence).
     Returns raw reward rows [R*L, B]."""
-    w, keep = weights if weights is not None else _lib.dis_weights(dis)
+    w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
     s, _ = _tokens(sentences, "sentences")
     comp, _ = _tokens(completions, "completions")
     R, L, B, L2 = comp.shape

@@ -17,6 +17,8 @@ from . import _lib, dist as tdist, ops
 class ROLLOUT:
     #: sequences scored per tg_dis_score call (bounds the pooled / dropout scratch)
     dis_chunk = 1 << 17
+    #: conv arithmetic of the scorer: None = library default ("split_f16"), or "fp32" (see TG_DIS_*)
+    dis_precision = None
 
     def __init__(self, gen, gpu=True):
         self.gen = gen
@@ -88,7 +90,7 @@ class ROLLOUT:
                 with self._timed("gen_rollout"):
                     comp = ops.gen_rollout(self.gen, sentences, Rl, u)
                 p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
-                weights = _lib.dis_weights(dis)
+                weights = _lib.dis_weights(dis, self.dis_precision)
                 F = weights[0].F
                 du_all = None
                 if p > 0 and dropout_uniforms is not None:
