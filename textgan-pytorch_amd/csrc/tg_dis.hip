@@ -305,6 +305,32 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
     }
 }
 
+__global__ __launch_bounds__(256) void k_split(const float* src, size_t n, _Float16* hi, _Float16* lo,
+                                               const float* scale) {
+    const float sc = *scale;
+    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
+        if (i + 4 <= n) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
+            f16x4 h, l;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x = v[e] * sc;
+                h[e] = (_Float16)x;
+                l[e] = (_Float16)(x - (float)h[e]);
+            }
+            *reinterpret_cast<f16x4*>(hi + i) = h;
+            *reinterpret_cast<f16x4*>(lo + i) = l;
+        } else {
+            for (size_t j = i; j < n; ++j) {
+                const float x = src[j] * sc;
+                const _Float16 h = (_Float16)x;
+                hi[j] = h;
+                lo[j] = (_Float16)(x - (float)h);
+            }
+        }
+    }
+}
+
 // Running max over time of the sentences' window values: cv[b][t][f] <- max_{t' <= t} cv[b][t'][f]
 // (entries with t >= L - f_k + 1 of a width are never read).
 __global__ __launch_bounds__(256) void k_dis_prefix_scan(float* cv, int B, int L, int F) {
@@ -369,6 +395,10 @@ __device__ __forceinline__ void hw_commit(const HwStage& st, float* dst, int tid
         *reinterpret_cast<f32x4*>(dst + (r0 + (kHwThreads / kHwCh) * i) * kHwStride + 4 * c) = st.v[i];
 }
 
+template <class ARGS>
+__device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][2], float (*red)[kHwTile][kMaxOut], int f0,
+                                            int s0, int bn, int wm, int wn, int n, int hh, int tid);
+
 __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dis_highway(const HwArgs a) {
     __shared__ __attribute__((aligned(16))) float As[kHwTile * kHwStride];  // hw_w rows (output features)
     __shared__ __attribute__((aligned(16))) float Bs[kHwTile * kHwStride];  // pooled rows (sequences)
@@ -427,6 +457,116 @@ __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
 
+    hw_epilogue(a, acc, red, f0, s0, bn, wm, wn, n, hh, tid);
+}
+
+// ---- highway GEMM on split-fp16 operands (both pre-split into (hi, lo) halves, see TG_DIS_SPLIT_F16)
+constexpr int kHsBK = 64;              // halves per tile row
+constexpr int kHsStride = kHsBK + 8;   // 144-B rows: 9 16-B slots (odd) -> conflict-free ds_read_b128
+struct HsArgs {
+    HwArgs h;
+    const _Float16* w_hi;   // [F,F] scaled hw_w, lo part F*F halves later
+    const _Float16* p_hi;   // [N,F] scaled pooled, lo part N*F halves later
+    const float* scales;    // {scale_w, scale_p, 1/(scale_w*scale_p)}
+};
+
+struct HsStage { f16x8 v[4]; };
+__device__ __forceinline__ void hs_fetch(HsStage& st, const _Float16* src, int row0, int nrows, int k0, int F, int tid) {
+    const int c = tid & 7, r0 = tid >> 3;  // 8 chunks of 8 halves per row, 32 rows per pass
+    const int k = k0 + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = tg_min(row0 + r0 + 32 * i, nrows - 1);
+        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (k < F) v = *reinterpret_cast<const f16x8*>(src + (size_t)row * F + k);
+        st.v[i] = v;
+    }
+}
+__device__ __forceinline__ void hs_commit(const HsStage& st, _Float16* dst, int tid) {
+    const int c = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(dst + (r0 + 32 * i) * kHsStride + 8 * c) = st.v[i];
+}
+
+__global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_dis_highway_split(const HsArgs a) {
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[kHwTile * kHsStride];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[kHwTile * kHsStride];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[kHwTile * kHsStride];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[kHwTile * kHsStride];
+    __shared__ float red[2][kHwTile][kMaxOut];
+
+    const int F = a.h.w.F;
+    const int tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv >> 1, wn = wv & 1;
+    const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int bn = blockIdx.x % a.h.nchunk, bm = blockIdx.x / a.h.nchunk;
+    const int f0 = bn * kHwTile, s0 = bm * kHwTile;
+    const size_t wlo = (size_t)F * F, plo = (size_t)a.h.N * F;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    HsStage sah, sal, sbh, sbl;
+    hs_fetch(sah, a.w_hi, f0, F, 0, F, tid);
+    hs_fetch(sal, a.w_hi + wlo, f0, F, 0, F, tid);
+    hs_fetch(sbh, a.p_hi, s0, a.h.N, 0, F, tid);
+    hs_fetch(sbl, a.p_hi + plo, s0, a.h.N, 0, F, tid);
+    for (int k0 = 0; k0 < F; k0 += kHsBK) {
+        __syncthreads();
+        hs_commit(sah, Ah, tid);
+        hs_commit(sal, Al, tid);
+        hs_commit(sbh, Bh, tid);
+        hs_commit(sbl, Bl, tid);
+        __syncthreads();
+        if (k0 + kHsBK < F) {
+            hs_fetch(sah, a.w_hi, f0, F, k0 + kHsBK, F, tid);
+            hs_fetch(sal, a.w_hi + wlo, f0, F, k0 + kHsBK, F, tid);
+            hs_fetch(sbh, a.p_hi, s0, a.h.N, k0 + kHsBK, F, tid);
+            hs_fetch(sbl, a.p_hi + plo, s0, a.h.N, k0 + kHsBK, F, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < kHsBK / 16; ++ks) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ao = (wm * 64 + i * 32 + n) * kHsStride + 16 * ks + 8 * hh;
+                const int bo = (wn * 64 + i * 32 + n) * kHsStride + 16 * ks + 8 * hh;
+                ah[i] = *reinterpret_cast<const f16x8*>(Ah + ao);
+                al[i] = *reinterpret_cast<const f16x8*>(Al + ao);
+                bh[i] = *reinterpret_cast<const f16x8*>(Bh + bo);
+                bl[i] = *reinterpret_cast<const f16x8*>(Bl + bo);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) {
+                    acc[i][jn] = TG_MFMA16(ah[i], bh[jn], acc[i][jn]);
+                    acc[i][jn] = TG_MFMA16(ah[i], bl[jn], acc[i][jn]);
+                    acc[i][jn] = TG_MFMA16(al[i], bh[jn], acc[i][jn]);
+                }
+        }
+    }
+    const float inv = a.scales[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    hw_epilogue(a.h, acc, red, f0, s0, bn, wm, wn, n, hh, tid);
+}
+
+template <class ARGS>
+__device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][2], float (*red)[kHwTile][kMaxOut], int f0,
+                                            int s0, int bn, int wm, int wn, int n, int hh, int tid) {
+    const int F = a.w.F, n_out = a.w.n_out;
     // ---- epilogue: gate, dropout, partial feature2out dot (lane = sequence, regs = features)
     float part[2][kMaxOut];
 #pragma unroll
@@ -654,14 +794,15 @@ size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
     const int nchunk = (w->F + kHwTile - 1) / kHwTile;
     return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut) +
            align256(sizeof(float) * (size_t)B_prefix * L * w->F) +
-           align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256;
+           align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256 +
+           align256(2 * sizeof(_Float16) * (size_t)N * w->F) + align256(2 * sizeof(_Float16) * (size_t)w->F * w->F);
 }
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
 // of all conv banks, the two power-of-two scales, and the (hi, lo) halves of the conv weights.
 int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, hipStream_t stream) {
     unsigned* absmax = (unsigned*)scal;          // [0] conv weights, [1] embedding table
-    float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e)}
+    float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e), -} x 2 (conv, highway)
     if (hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
         tg_set_error("hipMemsetAsync failed");
         return TG_ERR_LAUNCH;
@@ -726,6 +867,8 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut));
     _Float16* w16 = (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
     void* scal = (char*)w16 + align256(2 * sizeof(_Float16) * conv_weight_count(w));
+    _Float16* p16 = (_Float16*)((char*)scal + 256);
+    _Float16* hw16 = (_Float16*)((char*)p16 + align256(2 * sizeof(_Float16) * (size_t)N * w->F));
 
     // ---- conv
     ConvArgs ca = {};
@@ -777,9 +920,35 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     ha.N = N;
     ha.nchunk = nchunk;
     ha.nseqtile = (N + kHwTile - 1) / kHwTile;
-    tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
-    hipLaunchKernelGGL(k_dis_highway, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, ha);
-    tg_prof_end(stream);
+    if (w->precision == TG_DIS_SPLIT_F16 && (w->F & 7) == 0) {
+        // scales from |max| of hw_w and of the pooled features, then (hi, lo) halves of both operands
+        unsigned* absmax = (unsigned*)scal + 2;
+        float* scales = (float*)((char*)scal + 16) + 4;
+        const size_t nw = (size_t)w->F * w->F, np = (size_t)N * w->F;
+        tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 1024)), dim3(256), 0, stream, w->hw_w, nw,
+                           absmax);
+        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((np / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
+                           pooled, np, absmax + 1);
+        hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
+        hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((nw / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
+                           w->hw_w, nw, hw16, hw16 + nw, scales);
+        hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((np / 4 + 255) / 256) + 1, 4096)), dim3(256), 0, stream,
+                           (const float*)pooled, np, p16, p16 + np, scales + 1);
+        tg_prof_end(stream);
+        HsArgs hs = {};
+        hs.h = ha;
+        hs.w_hi = hw16;
+        hs.p_hi = p16;
+        hs.scales = scales;
+        tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
+        hipLaunchKernelGGL(k_dis_highway_split, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, hs);
+        tg_prof_end(stream);
+    } else {
+        tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
+        hipLaunchKernelGGL(k_dis_highway, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, ha);
+        tg_prof_end(stream);
+    }
 
     // ---- final: fixed-order partial sum, softmax column
     FinalArgs fa = {};
