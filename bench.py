@@ -23,21 +23,29 @@ sys.path.insert(0, ROOT)
 import textgan_pytorch_amd as tg  # noqa: E402
 
 WORKLOADS = {
-    # name: V, L, E, H, B, R per GPU
+    # name: V, L, E, H, B, R per GPU.  c2 is the default (the metric's config); the others are side runs.
     "c1": dict(V=5000, L=20, E=32, H=32, B=64, R=16, desc="configs[0] SeqGAN oracle synthetic"),
     "c2": dict(V=5255, L=51, E=32, H=32, B=64, R=16, desc="configs[1] SeqGAN real-data shape (EMNLP-News-like)"),
+    "c3s": dict(V=32000, L=51, E=512, H=512, B=4096, R=1, desc="configs[2] scaled rollout, 1/64 slice (rollout_num 1 of 64)"),
+    "c4": dict(V=5000, L=20, E=32, H=32, B=64, R=16, k=4, dis="sentigan",
+               desc="configs[3] SentiGAN k=4 generators, shared 5-way CNN_D, 4 sequential get_reward calls"),
 }
-PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
+PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md, Peak BF16/FP16 MFMA, dense
 
 
 def flops_model(V, L, E, H, filt, Ed=64, n_out=2):
-    """Algorithmic FLOPs."""
+    """Algorithmic FLOPs.  conv_fresh_per_bi is what the prefix-reuse scorer executes for
+    one (rollout i, sentence b) pair, i.e. summed over given_num g = 1..L: only windows t > g - f touch sampled
+    tokens; the others come from the per-sentence running-max table."""
     fs, ns = filt
     F = sum(ns)
     conv_per_seq = 2 * Ed * sum(n * f * (L - f + 1) for f, n in zip(fs, ns))
+    conv_fresh_per_bi = 2 * Ed * sum(n * f * sum((L - f + 1) - max(0, g - f + 1) for g in range(1, L + 1))
+                                     for f, n in zip(fs, ns))
     hw_per_seq = 2 * F * F + 2 * F * n_out
     gen_per_token = 2 * H * V + 2 * 4 * H * (E + H)
-    return conv_per_seq, hw_per_seq, gen_per_token
+    return conv_per_seq, conv_fresh_per_bi, hw_per_seq, gen_per_token
 
 
 def pmc_traffic(workload, kernel):
@@ -64,7 +72,10 @@ def cpu_baseline(wl, budget_s=15.0):
     from oracle import oracle
     V, L, B = wl["V"], wl["L"], wl["B"]
     gsd = tg.synth.gen_state(V, wl["E"], wl["H"], seed=0, std=1.0)
-    dsd = tg.synth.dis_state(V, 64, *tg.synth.SEQGAN_D_FILTERS, n_out=2, seed=0)
+    if wl.get("dis") == "sentigan":
+        dsd = tg.synth.dis_state(V, 64, *tg.synth.SENTIGAN_D_FILTERS, n_out=5, seed=0)
+    else:
+        dsd = tg.synth.dis_state(V, 64, *tg.synth.SEQGAN_D_FILTERS, n_out=2, seed=0)
     og, od = oracle.Gen(gsd), oracle.Dis(dsd)
     sent = tg.synth.tokens(1, (B, L), V)
 
@@ -72,7 +83,7 @@ def cpu_baseline(wl, budget_s=15.0):
         u = tg.synth.uniform01(2, (R, L, L, B))
         du = tg.synth.uniform01(3, (R * L * B, od.F))
         t0 = time.perf_counter()
-        oracle.get_reward(og, od, sent, R, u, dropout_p=0.25, dropout_uniforms=du)
+        oracle.get_reward(og, od, sent, R, u, dropout_p=0.25, dropout_uniforms=du)  # one generator's call
         return time.perf_counter() - t0
 
     t1 = run(1)
@@ -90,6 +101,8 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
+    ap.add_argument("--dis-precision", default=None, choices=["fp32", "split_f16"],
+                    help="scorer conv/highway arithmetic (default: the library default, split_f16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -107,14 +120,29 @@ def main():
     wl = WORKLOADS[args.workload]
     V, L, E, H, B = wl["V"], wl["L"], wl["E"], wl["H"], wl["B"]
     R = wl["R"] * world  # weak scaling: rollout_num 16 per GPU
-    gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=1.0, device=dev)
-    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=dev)
+    k_gens = wl.get("k", 1)
+    std = 1.0 if H == 32 else 0.05   # N(0,1) "oracle" weights (generator.py:97-100); small std at H = 512
+    gens = [tg.modules.synthetic_generator(V, E, H, L, seed=i, std=std, device=dev) for i in range(k_gens)]
+    dis_kind = wl.get("dis", "seqgan")
+    dis = tg.modules.synthetic_discriminator(dis_kind, V, seed=0, k_label=4, device=dev)
     if args.eval_mode:
         dis.eval()
     sent = torch.from_numpy(tg.synth.tokens(1, (B, L), V)).to(dev)
-    ro = tg.ROLLOUT(gen, True)
-    ro.generator = torch.Generator(device=dev)
-    ro.generator.manual_seed(1234 + rank)
+    ros = []
+    for gi, g in enumerate(gens):
+        ro = tg.ROLLOUT(g, True)
+        ro.generator = torch.Generator(device=dev)
+        ro.generator.manual_seed(1234 + rank + 100 * gi)
+        ro.dis_precision = args.dis_precision
+        ros.append(ro)
+
+    def step():
+        # SentiGAN (k generators, shared D): generators are visited sequentially, column current_k + 1
+        # (instructor/real_data/sentigan_instructor.py:137-147)
+        out = None
+        for gi, ro in enumerate(ros):
+            out = ro.get_reward(sent, R, dis, gi if k_gens > 1 else 0)
+        return out
 
     def barrier():
         if world > 1:
@@ -122,13 +150,13 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        ro.get_reward(sent, R, dis)
+        step()
     barrier()
     tg._lib.profile_enable(True)
     tg._lib.profile_read()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        rewards = ro.get_reward(sent, R, dis)
+        rewards = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = tg._lib.profile_read()
@@ -140,31 +168,41 @@ def main():
     assert tuple(rewards.shape) == (B, L) and bool(torch.isfinite(rewards).all())
 
     if rank == 0:
-        completions = B * R * L  # whole job, per step
-        conv_f, hw_f, gen_f = flops_model(V, L, E, H, tg.synth.SEQGAN_D_FILTERS)
-        n_local = B * wl["R"] * L  # sequences one rank's launches process
-        per_launch = {"dis_conv": conv_f * n_local, "dis_highway": hw_f * n_local,
+        completions = B * R * L * k_gens  # whole job, per step
+        filt = tg.synth.SENTIGAN_D_FILTERS if dis_kind == "sentigan" else tg.synth.SEQGAN_D_FILTERS
+        conv_f, conv_fresh_bi, hw_f, gen_f = flops_model(V, L, E, H, filt, n_out=dis.feature2out.out_features)
+        n_local = B * wl["R"] * L  # sequences one rank's launches process per get_reward call
+        split = (args.dis_precision or tg._lib.default_dis_precision) == "split_f16"
+        # flops one launch EXECUTES (prefix-reuse conv: fresh windows only); the reference-equivalent conv work
+        # (every window of every completion) is reported beside it
+        per_launch = {"dis_conv": conv_fresh_bi * B * wl["R"], "dis_highway": hw_f * n_local,
                       "gen_sample": gen_f * B * wl["R"] * L * (L - 1) // 2}
+        peaks = {"dis_conv": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
+                 "dis_highway": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
+                 "gen_sample": PEAK_FP32_MFMA_TFLOPS}
         kernels = {}
         for name, (ms, n) in prof.items():
             if n:
                 kernels[name] = {"avg_ms": ms / n, "launches": n}
                 if name in per_launch:
                     kernels[name]["tflops"] = per_launch[name] / (ms / n * 1e-3) / 1e12
-        dom = max(kernels, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
-        ach = kernels[dom].get("tflops", 0.0)
+                    kernels[name]["peak_tflops"] = peaks[name]
+        kernels["dis_conv"]["reference_equivalent_tflops"] = conv_f * n_local / (kernels["dis_conv"]["avg_ms"] * 1e-3) / 1e12
+        dom = max(per_launch, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+        ach = kernels[dom]["tflops"]
         out = {
             "metric": "MC rollout completions/sec", "value": completions * args.steps / dt, "unit": "completions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32 (scorer conv/highway: split-f16 x3, f32 accumulate)" if split else "f32", "data": "synthetic",
             "config": {"workload": "%s: vocab %d, len %d, emb/hidden %d, batch %d, rollout_num %d per GPU (%d total), "
-                                   "SeqGAN_D scorer%s" % (wl["desc"], V, L, H, B, wl["R"], R,
-                                                          " eval mode" if args.eval_mode else " with live dropout"),
+                                   "%s scorer%s" % (wl["desc"], V, L, H, B, wl["R"], R, dis_kind,
+                                                    " eval mode" if args.eval_mode else " with live dropout"),
                        "completions_per_step": completions, "sharding": "rollout index over %d rank(s)" % world},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+            "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peaks[dom],
+                         "unit": "TFLOP/s", "frac": ach / peaks[dom],
                          "traffic": pmc_traffic(args.workload, dom) if world == 1 else None,
-                         "flops_per_launch": per_launch.get(dom), "avg_launch_ms": kernels[dom]["avg_ms"]},
+                         "flops_per_launch": per_launch[dom], "avg_launch_ms": kernels[dom]["avg_ms"]},
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -70,7 +70,8 @@ struct GenArgs {
 // k pairs (j, 16+j), j = 0..15, then the bias), so that a recomputed logit reproduces
 // the MFMA result.
 template <int HT>
-__device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, const float* hrow, float bias) {
+__device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, const float* hrow, float bias,
+                                                float hscale = 1.f, bool bias_prescaled = false) {
     float acc = 0.f;
 #pragma unroll 2
     for (int c = 0; c < HT; ++c) {
@@ -80,11 +81,11 @@ __device__ __forceinline__ float dot_mfma_order(const float* __restrict__ wrow, 
         for (int i = 0; i < 4; ++i) { wl[i] = w4[i]; wh[i] = w4[4 + i]; }
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-            acc = __builtin_fmaf(wl[j >> 2][j & 3], hrow[32 * c + j], acc);
-            acc = __builtin_fmaf(wh[j >> 2][j & 3], hrow[32 * c + 16 + j], acc);
+            acc = __builtin_fmaf(wl[j >> 2][j & 3], hrow[32 * c + j] * hscale, acc);
+            acc = __builtin_fmaf(wh[j >> 2][j & 3], hrow[32 * c + 16 + j] * hscale, acc);
         }
     }
-    return acc + bias;  // the bias enters last, as one more k step (a = b_out[v], b = 1)
+    return acc + (bias_prescaled ? bias : bias * hscale);  // the bias enters last, as one more k step (a = b_out[v] * hscale, b = 1)
 }
 
 // 16 consecutive floats (64 B, 16-B aligned) -> registers
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     const int a_r = (am & 3) + 4 * (am >> 3);
     const int last_span = (V - 1) / Ls;
 
-    long long st_cell = 0, st_proj = 0, st_draw = 0, st_n = 0;
+    long long st_cell = 0, st_proj = 0, st_draw = 0, st_n = 0, st_d[4] = {0, 0, 0, 0};
     for (int t = t0; t < L; ++t) {
         const long long c0 = clock64();
         // ============================================================== LSTM cell
@@ -325,6 +326,11 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
 
         const long long c1 = clock64();
         // ============================================================== projection + online softmax
+        // The pipelined path works in base 2: h (B operand) and the bias are pre-multiplied by log2(e), so the
+        // MFMA delivers l' = l*log2(e) and a weight is one v_exp_f32 (1 ulp) of (l' - m'): 2 VALU per entry
+        // instead of 7.  Costs one extra fp32 rounding on h (same size as the GEMM's own rounding noise).
+        const bool b2 = REG && (SAMPLE || !a.logits_out);
+        const float kL2E = 1.44269502162933349609375f;
         float m_run = TG_NEG_BIG;  // finite sentinel: exp(TG_NEG_BIG - m) is exactly 0, never NaN
         float c_grp = 0.f;         // SAMPLE: current group's sum at scale m_run; TF: running sum of the span
         const int sp_lo = sp * Ls;
@@ -405,17 +411,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // k = 0 lanes (against b = 1): one dword per lane instead of a 64-B broadcast bias read.
                     struct AFrag { float w[16]; float bias; };
                     const float bone = hh ? 0.f : 1.f;
+                    float hb2[16];
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) hb2[j] = hb[j] * kL2E;
                     auto load_a = [&](int q, AFrag& dst) {
                         const int v = a_sp * Ls + 16 * q + a_r;
                         load16(a.w.w_out + (size_t)tg_min(v, V - 1) * kH + 16 * hh, dst.w);
-                        dst.bias = hh ? 0.f : (v < V ? a.w.b_out[v] : TG_NEG_BIG);
+                        dst.bias = hh ? 0.f : (v < V ? a.w.b_out[v] * kL2E : TG_NEG_BIG);
                     };
                     auto mfma_tile = [&](int q, const AFrag& af) {
                         f32x16 acc;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(af.w[j], hb[j], acc);
+                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(af.w[j], hb2[j], acc);
                         acc = TG_MFMA32(af.bias, bone, acc);
                         return acc;
                     };
@@ -427,9 +436,10 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                         // branch-free group restart (a select on the scalar condition would split the block
                         // and serialise the MFMA chain ahead of this VALU work)
                         const float keep = (SAMPLE && (q & gk_mask) == 0) ? 0.f : 1.f;
-                        c_grp = c_grp * tg_expf_neg(m_run - m_new) * keep;
+                        c_grp = c_grp * __builtin_amdgcn_exp2f(m_run - m_new) * keep;
                         float ev[16];
-                        tg_exp16_neg(acc, m_new, ev);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(acc[r] - m_new);
                         float ts = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) ts += ev[r];  // canonical order: sequential
@@ -438,39 +448,43 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                         // stored after every tile: the group's last tile leaves the final value
                         if (SAMPLE) rec[((q >> gk_shift) * kNSpan + sp) * kRows + n] = make_float2(m_run, c_grp);
                     };
+                    // ask the scheduler for 1 MFMA : 6 VALU in program order (the in-order wave otherwise parks
+                    // on the dependent MFMA chain with the softmax work queued behind it)
+                    auto interleave = [&]() {
+#pragma unroll
+                        for (int i = 0; i < 17; ++i) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+                        }
+                    };
                     if (nfull > 0) {
-                        AFrag a0, a1;
+                        // A fragments are fetched three tiles ahead (an L2 round trip under load is ~2 tiles long)
+                        AFrag a0, a1, a2;
                         f32x16 acc0, acc1;
                         load_a(0, a0);
                         if (nfull > 1) load_a(1, a1);
+                        if (nfull > 2) load_a(2, a2);
                         acc0 = mfma_tile(0, a0);
                         int q = 0;
-                        // ask the scheduler for 1 MFMA : 10 VALU in program order (the in-order wave otherwise
-                        // parks on the dependent MFMA chain with the softmax work queued behind it)
-                        auto interleave = [&]() {
-#pragma unroll
-                            for (int i = 0; i < 17; ++i) {
-                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
-                                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);  // VALU
-                            }
-                        };
-                        for (; q + 2 < nfull; q += 2) {
-                            load_a(q + 2, a0);
-                            acc1 = mfma_tile(q + 1, a1);
-                            softmax_tile(acc0, q);
-                            interleave();
-                            if (q + 3 < nfull) load_a(q + 3, a1);
-                            acc0 = mfma_tile(q + 2, a0);
-                            softmax_tile(acc1, q + 1);
-                            interleave();
+                        // invariant at loop head: acc0 = tile q (q % 6 == 0), a1 = tile q+1, a2 = tile q+2 in flight
+                        for (; q + 6 < nfull; q += 6) {
+                            load_a(q + 3, a0); acc1 = mfma_tile(q + 1, a1); softmax_tile(acc0, q);     interleave();
+                            load_a(q + 4, a1); acc0 = mfma_tile(q + 2, a2); softmax_tile(acc1, q + 1); interleave();
+                            load_a(q + 5, a2); acc1 = mfma_tile(q + 3, a0); softmax_tile(acc0, q + 2); interleave();
+                            load_a(q + 6, a0); acc0 = mfma_tile(q + 4, a1); softmax_tile(acc1, q + 3); interleave();
+                            if (q + 7 < nfull) load_a(q + 7, a1);
+                            acc1 = mfma_tile(q + 5, a2); softmax_tile(acc0, q + 4); interleave();
+                            if (q + 8 < nfull) load_a(q + 8, a2);
+                            acc0 = mfma_tile(q + 6, a0); softmax_tile(acc1, q + 5); interleave();
                         }
-                        // q is even here, acc0 holds tile q; one or two tiles remain
-                        if (q + 1 < nfull) {
-                            acc1 = mfma_tile(q + 1, a1);
-                            softmax_tile(acc0, q);
-                            softmax_tile(acc1, q + 1);
-                        } else {
-                            softmax_tile(acc0, q);
+                        // tail (at most 6 tiles): acc0 = tile q; a1 = tile q+1, a2 = tile q+2 if they exist
+                        softmax_tile(acc0, q);
+                        if (q + 1 < nfull) { acc1 = mfma_tile(q + 1, a1); softmax_tile(acc1, q + 1); }
+                        if (q + 2 < nfull) { acc0 = mfma_tile(q + 2, a2); softmax_tile(acc0, q + 2); }
+                        for (int qq = q + 3; qq < nfull; ++qq) {
+                            load_a(qq, a0);
+                            acc0 = mfma_tile(qq, a0);
+                            softmax_tile(acc0, qq);
                         }
                     }
                     q_done = nfull;
@@ -488,19 +502,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const long long c2 = clock64();
         mbuf[sp * kRows + n] = m_run;
         __syncthreads();
+        const long long d0 = clock64();
         float M = mbuf[n];
 #pragma unroll
         for (int s = 1; s < kNSpan; ++s) M = __builtin_fmaxf(M, mbuf[s * kRows + n]);
 
         if (!SAMPLE) {
             // ---------------------------------------------------------- teacher forced: lse + picked log-prob
-            sbuf[sp * kRows + n] = (double)c_grp * exp((double)(m_run - M));  // empty span: c_grp = 0
+            sbuf[sp * kRows + n] = (double)c_grp * (b2 ? exp2((double)(m_run - M)) : exp((double)(m_run - M)));  // empty span: c_grp = 0
             __syncthreads();
             if (tid < kRows) {
                 double S = 0.0;
 #pragma unroll
                 for (int s = 0; s < kNSpan; ++s) S += sbuf[s * kRows + n];
-                const float lse = (float)((double)M + log(S));
+                const float lse = b2 ? (float)(((double)M + log2(S)) * 0.69314718055994530942) : (float)((double)M + log(S));
                 if (valid) {
                     const size_t o = tf_row * L + t;
                     if (a.lse_out) a.lse_out[o] = lse;
@@ -524,14 +539,18 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const int sp_hi = tg_min(V, sp_lo + Ls);
         const int ng_valid = (sp_hi > sp_lo) ? (sp_hi - sp_lo + EG - 1) / EG : 0;
         {
-            double s = 0.0;
+            // the running max of a span settles early: consecutive records mostly share their scale factor
+            double s = 0.0, fac = 1.0;
+            float fx = M;
             for (int q = 0; q < ng_valid; ++q) {
                 const float2 r = rec[(q * kNSpan + sp) * kRows + n];
-                s += (double)r.y * exp((double)(r.x - M));
+                if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
+                s += (double)r.y * fac;
             }
             sbuf[sp * kRows + n] = s;
         }
         __syncthreads();
+        const long long d1 = clock64();
         {
             double S = 0.0;
 #pragma unroll
@@ -546,9 +565,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
             if (sel == sp) {  // exactly one of the row's 8 threads owns the draw
                 int gq = ng_valid - 1;
+                double fac = 1.0;
+                float fx = M;
                 for (int q = 0; q < ng_valid; ++q) {
                     const float2 r = rec[(q * kNSpan + sp) * kRows + n];
-                    const double c = (double)r.y * exp((double)(r.x - M));
+                    if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
+                    const double c = (double)r.y * fac;
                     if (p + c > target || q == ng_valid - 1) { gq = q; break; }
                     p += c;
                 }
@@ -559,20 +581,46 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             }
         }
         __syncthreads();  // selections visible; every read of rec is done (wbuf / xbuf alias-free from here)
-        // cooperative recompute of the chosen groups: 32 rows x EG entries over 256 threads
-        for (int idx = tid; idx < kRows * EG; idx += kThreads) {
-            const int rr = idx / EG, e = idx - rr * EG;
+        const long long d2 = clock64();
+        // cooperative recompute of the chosen groups: 8 threads per row, each EG/8 entries of that row with the
+        // row's h held in registers (REG) or read from LDS per chunk
+        {
+            const int rr = tid >> 3, e0 = tid & 7;
             const int gv = selv[rr];
             const int vend = tg_min(V, (gv / Ls + 1) * Ls);
-            const int v = gv + e;
-            float wv = 0.f;
-            if (v < vend) {
-                const float lg = dot_mfma_order<HT>(a.w.w_out + (size_t)v * kH, hbuf + rr * kHStride, a.w.b_out[v]);
-                wv = tg_expf(lg - Mbuf[rr]);
+            const float Mr = Mbuf[rr];
+            const float hs = b2 ? kL2E : 1.f;
+            if constexpr (REG) {
+                float hrow[32];
+#pragma unroll
+                for (int q4 = 0; q4 < 8; ++q4) {
+                    const f32x4 v4 = *reinterpret_cast<const f32x4*>(hbuf + rr * kHStride + 4 * q4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) hrow[4 * q4 + e] = v4[e] * hs;
+                }
+                for (int e = e0; e < EG; e += 8) {
+                    const int v = gv + e;
+                    float wv = 0.f;
+                    if (v < vend) {
+                        const float lg = dot_mfma_order<1>(a.w.w_out + (size_t)v * kH, hrow, a.w.b_out[v] * hs, 1.f, true);
+                        wv = b2 ? __builtin_amdgcn_exp2f(lg - Mr) : tg_expf(lg - Mr);
+                    }
+                    wbuf[rr * (EG + 1) + e] = wv;
+                }
+            } else {
+                for (int e = e0; e < EG; e += 8) {
+                    const int v = gv + e;
+                    float wv = 0.f;
+                    if (v < vend) {
+                        const float lg = dot_mfma_order<HT>(a.w.w_out + (size_t)v * kH, hbuf + rr * kHStride, a.w.b_out[v]);
+                        wv = tg_expf(lg - Mr);
+                    }
+                    wbuf[rr * (EG + 1) + e] = wv;
+                }
             }
-            wbuf[rr * (EG + 1) + e] = wv;
         }
         __syncthreads();
+        const long long d3 = clock64();
         if (tid < kRows) {
             const int gv = selv[n];
             const int vend = tg_min(V, (gv / Ls + 1) * Ls);
@@ -603,10 +651,12 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         tok = tokbuf[n];
         const long long c3 = clock64();
         st_cell += c1 - c0; st_proj += c2 - c1; st_draw += c3 - c2; st_n += 1;
+        st_d[0] += d0 - c2; st_d[1] += d1 - d0; st_d[2] += d2 - d1; st_d[3] += d3 - d2;
     }
     if (SAMPLE && a.stamps && tid == 0) {
-        long long* o = a.stamps + (size_t)blockIdx.x * 4;
+        long long* o = a.stamps + (size_t)blockIdx.x * 8;
         o[0] = st_cell; o[1] = st_proj; o[2] = st_draw; o[3] = st_n;
+        o[4] = st_d[0]; o[5] = st_d[1]; o[6] = st_d[2]; o[7] = st_d[3];
     }
 }
 
