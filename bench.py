@@ -48,6 +48,9 @@ def flops_model(V, L, E, H, filt, Ed=64, n_out=2):
     return conv_per_seq, conv_fresh_per_bi, hw_per_seq, gen_per_token
 
 
+PROFILE_NAME = {"gen_sample": "k_gen<true", "gen_teacher": "k_gen<false"}   # kernel symbols in rocprofv3 output
+
+
 def pmc_traffic(workload, kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/*_hbm_traffic.json,
     made by tools/summarize_prof.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command), or None."""
@@ -61,7 +64,7 @@ def pmc_traffic(workload, kernel):
         if d.get("workload") != workload:
             continue
         for name, v in d.get("kernels", {}).items():
-            if name.startswith("k_" + kernel):
+            if name.startswith(PROFILE_NAME.get(kernel, "k_" + kernel)):
                 best = v.get("hbm_bytes_per_launch")
     return best
 

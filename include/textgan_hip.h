@@ -64,10 +64,10 @@ typedef struct TgDisWeights {
     int32_t n[TG_MAX_FILTERS];            /* filters per width n_k   */
     int32_t n_filters;                    /* number of widths        */
     int32_t V, Ed, F, n_out;
-    int32_t precision;                    /* TG_DIS_FP32 or TG_DIS_SPLIT_F16 (conv arithmetic) */
+    int32_t precision;                    /* TG_DIS_FP32 or TG_DIS_SPLIT_F16 (conv + highway)   */
 } TgDisWeights;
 
-/* Arithmetic of the scorer's convolutions (the highway and the output layer are always fp32):
+/* Arithmetic of the scorer's convolutions and highway GEMM (gate, dropout, output layer, softmax: always fp32):
  *   TG_DIS_FP32       exact fp32 (v_mfma_f32_32x32x2_f32)
  *   TG_DIS_SPLIT_F16  each operand x*2^k = hi + lo in fp16 (22 mantissa bits), three fp16 MFMAs with fp32
  *                     accumulation per product (hi.hi + hi.lo + lo.hi): ~5e-7 relative per product,

@@ -135,12 +135,13 @@ def test_rollout_subranges_and_mc_search():
 
 
 # ------------------------------------------------------------------ discriminator
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
 @pytest.mark.parametrize("name", _cases.names("dis"))
-def test_discriminator(name):
+def test_discriminator(name, precision):
     c = _cases.load(name)
     dis = _dis(c).eval()
     seqs = synth.tokens(int(c["sseed"]), (int(c["N"]), int(c["L"])), int(c["V"]))
-    r = tg.ops.dis_score(dis, _t(seqs), want_logits=True, want_feature=True)
+    r = tg.ops.dis_score(dis, _t(seqs), want_logits=True, want_feature=True, precision=precision)
     np.testing.assert_allclose(r["feature"].cpu().numpy(), c["feature"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(r["logits"].cpu().numpy(), c["logits"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(tg.discriminator.forward(dis, _t(seqs)).cpu().numpy(), c["logits"], rtol=1e-4, atol=2e-6)
@@ -151,8 +152,9 @@ def test_discriminator(name):
             tg.ops.dis_score(dis, _t(seqs[:, :3]))
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
 @pytest.mark.parametrize("N", [1, 5, 129, 300])
-def test_discriminator_ragged_and_dropout(N):
+def test_discriminator_ragged_and_dropout(N, precision):
     V, L = 97, 23
     sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=9)
     dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), sd, DEV)
@@ -161,7 +163,7 @@ def test_discriminator_ragged_and_dropout(N):
     du = synth.uniform01(N + 1, (N, od.F))
     o = oracle.dis_forward(od, seqs, col=1, dropout_p=0.25, dropout_uniforms=du, want_feature=True)
     r = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=0.25, dropout_uniforms=_t(du), want_logits=True,
-                         want_feature=True)
+                         want_feature=True, precision=precision)
     np.testing.assert_allclose(r["feature"].cpu().numpy(), o["feature"], rtol=1e-4, atol=2e-6)
     np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-4, atol=5e-6)
     np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
@@ -198,8 +200,9 @@ def test_get_reward(name):
     np.testing.assert_allclose(red, c["raw"].reshape(B, L, R).mean(-1), atol=1e-6, rtol=0)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
 @pytest.mark.parametrize("name", ["reward_senti_k2", "reward_tiny_dropout", "reward_len51", "reward_c2_r1"])
-def test_prefix_reuse_scorer_is_bit_identical(name):
+def test_prefix_reuse_scorer_is_bit_identical(name, precision):
     """tg_dis_score_rollout (conv windows inside the shared prefix evaluated once per sentence) against the plain
     scorer on the same completions: identical bits, including B not a multiple of the workgroup's sequence count."""
     c = _cases.load(name)
@@ -210,11 +213,25 @@ def test_prefix_reuse_scorer_is_bit_identical(name):
     p = float(c["dropout_p"])
     dut = None if du is None else _t(du.reshape(R * L * B, -1))
     plain = tg.ops.dis_score(dis, comp.view(R * L * B, L), col=int(c["current_k"]) + 1, dropout_p=p,
-                             dropout_uniforms=dut)["reward"].view(R * L, B)
+                             dropout_uniforms=dut, precision=precision)["reward"].view(R * L, B)
     fast = tg.ops.dis_score_rollout(dis, _t(sent), comp, col=int(c["current_k"]) + 1, dropout_p=p,
-                                    dropout_uniforms=dut)
+                                    dropout_uniforms=dut, precision=precision)
     assert torch.equal(plain, fast)
     np.testing.assert_allclose(fast.cpu().numpy(), c["raw"], atol=1e-4, rtol=0)
+
+
+def test_split_precision_against_fp32():
+    """The default split-fp16 x3 scorer against the exact-fp32 scorer on the same inputs at C2's shape: pooled
+    features / logits within 2e-5 relative (measured ~2e-6), rewards within 1e-5."""
+    V, L, N = 5255, 51, 2048
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=3, device=DEV).eval()
+    seqs = _t(synth.tokens(5, (N, L), V))
+    a = tg.ops.dis_score(dis, seqs, want_logits=True, want_feature=True, precision="fp32")
+    b = tg.ops.dis_score(dis, seqs, want_logits=True, want_feature=True, precision="split_f16")
+    scale = float(a["feature"].abs().max())
+    assert float((a["feature"] - b["feature"]).abs().max()) <= 2e-5 * scale
+    assert float((a["logits"] - b["logits"]).abs().max()) <= 2e-5 * max(1.0, float(a["logits"].abs().max()))
+    assert float((a["reward"] - b["reward"]).abs().max()) <= 1e-5
 
 
 def test_get_reward_c1_full_vs_oracle():
