@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
     ap.add_argument("--dis-precision", default=None, choices=["fp32", "split_f16"],
                     help="scorer conv/highway arithmetic (default: the library default, split_f16)")
+    ap.add_argument("--gen-precision", default=None, choices=["fp32", "split_f16"],
+                    help="generator vocabulary-projection arithmetic (default: the library default, split_f16)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -137,6 +139,7 @@ def main():
         ro.generator = torch.Generator(device=dev)
         ro.generator.manual_seed(1234 + rank + 100 * gi)
         ro.dis_precision = args.dis_precision
+        ro.gen_precision = args.gen_precision
         ros.append(ro)
 
     def step():
@@ -176,13 +179,17 @@ def main():
         conv_f, conv_fresh_bi, hw_f, gen_f = flops_model(V, L, E, H, filt, n_out=dis.feature2out.out_features)
         n_local = B * wl["R"] * L  # sequences one rank's launches process per get_reward call
         split = (args.dis_precision or tg._lib.default_dis_precision) == "split_f16"
+        gsplit = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and E == 32 and H == 32
         # flops one launch EXECUTES (prefix-reuse conv: fresh windows only); the reference-equivalent conv work
         # (every window of every completion) is reported beside it
         per_launch = {"dis_conv": conv_fresh_bi * B * wl["R"], "dis_highway": hw_f * n_local,
                       "gen_sample": gen_f * B * wl["R"] * L * (L - 1) // 2}
         peaks = {"dis_conv": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
                  "dis_highway": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
-                 "gen_sample": PEAK_FP32_MFMA_TFLOPS}
+                 "gen_sample": PEAK_F16_MFMA_TFLOPS if gsplit else PEAK_FP32_MFMA_TFLOPS}
+        # split-f16 kernels issue three fp16 MFMA products per algorithmic multiply-add
+        issue_factor = {"dis_conv": 3 if split else 1, "dis_highway": 3 if split else 1,
+                        "gen_sample": 3 if gsplit else 1}
         kernels = {}
         for name, (ms, n) in prof.items():
             if n:
@@ -190,6 +197,7 @@ def main():
                 if name in per_launch:
                     kernels[name]["tflops"] = per_launch[name] / (ms / n * 1e-3) / 1e12
                     kernels[name]["peak_tflops"] = peaks[name]
+                    kernels[name]["mfma_products_per_flop"] = issue_factor[name]
         kernels["dis_conv"]["reference_equivalent_tflops"] = conv_f * n_local / (kernels["dis_conv"]["avg_ms"] * 1e-3) / 1e12
         dom = max(per_launch, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
         ach = kernels[dom]["tflops"]
@@ -197,7 +205,9 @@ def main():
             "metric": "MC rollout completions/sec", "value": completions * args.steps / dt, "unit": "completions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (scorer conv/highway: split-f16 x3, f32 accumulate)" if split else "f32", "data": "synthetic",
+            "dtype": "f32" + (" (split-f16 x3 operands, f32 accumulate: %s)" % ", ".join(
+                (["generator projection"] if gsplit else []) + (["scorer conv/highway"] if split else []))
+                if (split or gsplit) else ""), "data": "synthetic",
             "config": {"workload": "%s: vocab %d, len %d, emb/hidden %d, batch %d, rollout_num %d per GPU (%d total), "
                                    "%s scorer%s" % (wl["desc"], V, L, H, B, wl["R"], R, dis_kind,
                                                     " eval mode" if args.eval_mode else " with live dropout"),

@@ -46,8 +46,18 @@ typedef struct TgGenWeights {
     const float* w_out;  /* [V, H]   */
     const float* b_out;  /* [V]      */
     int32_t V, E, H;
-    int32_t _pad;
+    int32_t precision;   /* TG_GEN_FP32 or TG_GEN_SPLIT_F16 (vocabulary projection of the sampling kernels) */
 } TgGenWeights;
+
+/* Arithmetic of the vocabulary projection h.W_out^T inside tg_gen_rollout / tg_gen_sample (the LSTM cell, the
+ * softmax, the sampler's prefix sums and everything in tg_gen_teacher_forced are fp32 / fp64 regardless):
+ *   TG_GEN_FP32       exact fp32 (v_mfma_f32_32x32x2_f32)
+ *   TG_GEN_SPLIT_F16  operands scaled by a power of two and split into fp16 hi + lo (22 mantissa bits), three
+ *                     fp16 MFMAs per product with fp32 accumulation, bias added exactly; logits move by ~1e-6.
+ *                     Takes effect for E = H = 32 (every SeqGAN / SentiGAN config of the reference); other
+ *                     shapes compute in fp32. */
+#define TG_GEN_FP32 0
+#define TG_GEN_SPLIT_F16 1
 
 /* CNNDiscriminator parameters: models/discriminator.py:30-36 (state_dict keys
  * embeddings.weight, convs.k.weight [n_k,1,f_k,Ed], convs.k.bias,
@@ -122,11 +132,12 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
  *                            drawn token is still what is written, but the
  *                            token fed to the next step is forced[...], so one
  *                            fp32 CDF tie does not cascade down the row.
- *   workspace   prefix states, tg_gen_rollout_workspace_bytes(B,L,H) bytes.
+ *   workspace   prefix states (+ the split projection's W_out fragments),
+ *               tg_gen_rollout_workspace_bytes(w,B,L) bytes.
  * Sampling is inverse-CDF in the canonical order documented in DESIGN.md
  * ("canonical sampler") -- it replaces torch.multinomial(exp(out),1)
  * (utils/rollout.py:49). */
-size_t tg_gen_rollout_workspace_bytes(int B, int L, int H);
+size_t tg_gen_rollout_workspace_bytes(const TgGenWeights* w, int B, int L);
 int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B,
                    int L, int R, int g_lo, int g_hi, int i_lo, int i_hi,
                    const float* uniforms, const int64_t* forced,
@@ -139,10 +150,12 @@ int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B,
  * for N rows at once: zero state, first input `start_letter`.
  *   uniforms [L,N] fp32: draw for row n at position t is uniforms[t*N + n]
  *   forced   [N,L] int64 or NULL (replay mode, as in tg_gen_rollout)
- *   out      [N,L] int64 */
+ *   out      [N,L] int64
+ *   workspace  tg_gen_sample_workspace_bytes(w) bytes (0 for TG_GEN_FP32: may be NULL) */
+size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w);
 int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
                   const float* uniforms, const int64_t* forced, int64_t* out,
-                  void* stream);
+                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * CNN discriminator scorer.

@@ -82,14 +82,18 @@ def test_teacher_forced_ragged_rows():
 
 
 # ------------------------------------------------------------------ generator, sampling
+GEN_PRECISIONS = ["fp32", "split_f16"]  # TG_GEN_*: split applies to E = H = 32, other shapes run fp32 either way
+
+
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
 @pytest.mark.parametrize("name", _cases.names("get_reward"))
-def test_rollout_tokens(name):
+def test_rollout_tokens(name, precision):
     c = _cases.load(name)
     gen = _gen(c)
     sent, u, _ = _cases.reward_inputs(c)
     R = int(c["R"])
     ref = c["completions"].astype(np.int64)
-    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref)).cpu().numpy()
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision=precision).cpu().numpy()
     og = oracle.Gen(_cases.gen_sd(c))
     _cases.check_token_parity(replay, ref, u, og)
     # against the oracle's own replay as well (same forced tokens)
@@ -97,12 +101,13 @@ def test_rollout_tokens(name):
     m = _cases.sampled_mask(*ref.shape[:3])
     assert (replay[m] == orep[m]).mean() >= 0.999
     # free running: whole rows identical for the vast majority (a tie cascades down its row)
-    free = tg.ops.gen_rollout(gen, _t(sent), R, _t(u)).cpu().numpy()
+    free = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), precision=precision).cpu().numpy()
     assert (free == ref).all(-1).mean() >= 0.98
 
 
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
 @pytest.mark.parametrize("name", _cases.names("sample"))
-def test_sample(name):
+def test_sample(name, precision):
     c = _cases.load(name)
     gen = _gen(c)
     ns, batch, L = int(c["num_samples"]), int(c["batch"]), int(c["L"])
@@ -111,7 +116,8 @@ def test_sample(name):
     u = synth.uniform01(int(c["useed"]), (L, N))
     forced = np.zeros((N, L), np.int64)
     forced[:ns] = c["samples"]
-    out = tg.ops.gen_sample(gen, N, L, int(c["start_letter"]), _t(u), forced=_t(forced)).cpu().numpy()[:ns]
+    out = tg.ops.gen_sample(gen, N, L, int(c["start_letter"]), _t(u), forced=_t(forced),
+                            precision=precision).cpu().numpy()[:ns]
     assert (out == c["samples"]).mean() >= 0.999
     s = tg.generator.sample(gen, ns, batch, int(c["start_letter"]), uniforms=_t(u))
     assert s.device.type == "cpu" and s.dtype == torch.int64 and tuple(s.shape) == (ns, L)
@@ -234,7 +240,8 @@ def test_split_precision_against_fp32():
     assert float((a["reward"] - b["reward"]).abs().max()) <= 1e-5
 
 
-def test_get_reward_c1_full_vs_oracle():
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+def test_get_reward_c1_full_vs_oracle(precision):
     """BASELINE config 1 at full size (V5000 L20 E=H=32 B64 R16): 20 480 completions against the
     oracle; step-wise token parity, and rewards on rows whose completions agree."""
     V, L, B, R = 5000, 20, 64, 16
@@ -246,9 +253,11 @@ def test_get_reward_c1_full_vs_oracle():
     u = synth.uniform01(2, (R, L, L, B))
     og, od = oracle.Gen(gsd), oracle.Dis(dsd)
     o = oracle.get_reward(og, od, sent, R, u)
-    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"])).cpu().numpy()
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"]), precision=precision).cpu().numpy()
     _cases.check_token_parity(replay, o["completions"], u, og, max_check=50)
-    rew, raw, comp = tg.ROLLOUT(gen).get_reward(_t(sent), R, dis, uniforms=_t(u), return_parts=True)
+    ro = tg.ROLLOUT(gen)
+    ro.gen_precision = precision
+    rew, raw, comp = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), return_parts=True)
     same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
     assert same.mean() >= 0.98
     np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)

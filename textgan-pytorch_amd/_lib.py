@@ -14,7 +14,8 @@ MAX_FILTERS = 16
 MAX_OUT = 8
 
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
-           "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample", "tg_dis_workspace_bytes",
+           "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
+           "tg_dis_workspace_bytes",
            "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_reward_reduce",
            "tg_profile_enable", "tg_profile_read"]
 
@@ -24,7 +25,7 @@ KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "
 
 class GenW(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")] + \
-               [("V", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("_pad", C.c_int32)]
+               [("V", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32)]
 
 
 class DisW(C.Structure):
@@ -49,13 +50,16 @@ def lib():
         l.tg_version.restype = C.c_char_p
         l.tg_last_error.restype = C.c_char_p
         l.tg_gen_rollout_workspace_bytes.restype = C.c_size_t
+        l.tg_gen_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.tg_gen_sample_workspace_bytes.restype = C.c_size_t
+        l.tg_gen_sample_workspace_bytes.argtypes = [C.c_void_p]
         l.tg_dis_workspace_bytes.restype = C.c_size_t
         l.tg_dis_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.tg_gen_teacher_forced.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5
         l.tg_gen_rollout.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 7 + [C.c_void_p] * 4 + [C.c_size_t,
                                                                                                   C.c_void_p]
         l.tg_gen_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                    C.c_void_p]
+                                    C.c_void_p, C.c_size_t, C.c_void_p]
         l.tg_dis_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5 + \
                                   [C.c_size_t, C.c_void_p]
         l.tg_dis_score_rollout_workspace_bytes.restype = C.c_size_t
@@ -105,7 +109,13 @@ def _param(p, name):
     return d, dev_ptr(d, torch.float32, name)
 
 
-def gen_weights(gen):
+PRECISIONS = {"fp32": 0, "split_f16": 1}
+#: arithmetic used when a caller does not say: see TG_GEN_* / TG_DIS_* in include/textgan_hip.h
+default_gen_precision = "split_f16"
+default_dis_precision = "split_f16"
+
+
+def gen_weights(gen, precision=None):
     """Pack the live parameters of an LSTMGenerator-shaped module (models/generator.py:33-35).
     Read on every call: the generator is stepped between get_reward calls."""
     keep = []
@@ -121,16 +131,11 @@ def gen_weights(gen):
     H = keep[2].shape[1]
     if keep[1].shape != (4 * H, E) or keep[5].shape != (V, H):
         raise RuntimeError("textgan_hip: generator parameter shapes are inconsistent")
-    w = GenW(*ptrs, V, E, H, 0)
+    w = GenW(*ptrs, V, E, H, PRECISIONS[precision or default_gen_precision])
     if lib().tg_gen_supported(V, E, H) != 0:
         raise RuntimeError("textgan_hip: generator shape V=%d E=%d H=%d is not supported by the compiled kernels "
-                           "(E = H = 32)" % (V, E, H))
+                           "(H in {32,64,128,256,512}, E a multiple of 32)" % (V, E, H))
     return w, keep
-
-
-PRECISIONS = {"fp32": 0, "split_f16": 1}
-#: conv arithmetic used when a caller does not say: see TG_DIS_* in include/textgan_hip.h
-default_dis_precision = "split_f16"
 
 
 def dis_weights(dis, precision=None):

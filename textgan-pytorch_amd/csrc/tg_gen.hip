@@ -29,9 +29,17 @@
 
 namespace {
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_{f16,bf16}: A lane l -> A[i=l&31][k=8*(l>>5)+0..7]; B lane l -> B[k=8*(l>>5)+0..7][j=l&31];
+// D as for 32x32x2.  32 cycles per SIMD.
+#define TG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+#define TG_MFMA16BF(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+
 constexpr int kRows = 32;     // rows per workgroup (MFMA N)
 constexpr int kThreads = 256; // 4 waves
 constexpr int kNSpan = 8;
+constexpr float kGenHScale = 8192.f;  // split projection: |h * log2(e)| < 1.4427 -> below 2^14 in fp16
 
 struct SamplerGeom {
     int Ls;  // span length (entries)
@@ -62,6 +70,9 @@ struct GenArgs {
     float* logits_out;         // [N,L,V] or null
     float* states_out;         // [L+1,N,2,H] or null
     int need_proj;
+    // ---- split-fp16 projection (TG_GEN_SPLIT_F16): W_out as MFMA A fragments in load order, see k_gen_make_frag
+    const f32x4* frag;         // [4 waves][NT tiles][5][64 lanes] 16-B pieces
+    const float* gscale;       // [0] = W_out scale, [1] = h scale, [2] = 1/(both)
     long long* stamps;  // diagnostic (TG_STAMPS env = device pointer): per-workgroup s_memtime sums [grid][4]
 };
 
@@ -101,8 +112,9 @@ __device__ __forceinline__ void load16(const float* p, float (&dst)[16]) {
 
 __device__ __forceinline__ int clamp_tok(int64_t t, int V) { return tg_min(tg_max((int)t, 0), V - 1); }
 
-template <bool SAMPLE, int HT, bool REG>
+template <bool SAMPLE, int HT, bool REG, bool SPLIT>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gen(const GenArgs a) {
+    static_assert(!SPLIT || (SAMPLE && REG), "the split-fp16 projection exists for the E = H = 32 sampling kernel");
     constexpr int kH = 32 * HT;
     constexpr int kHStride = kH + 4;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
     static_assert(!REG || HT == 1, "register-resident operands need H = 32");
@@ -407,31 +419,70 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                     // the bias operand (TG_NEG_BIG -> weight exactly 0), so the tail needs no separate path.
                     const int nfull = NT;
                     const int gk_mask = GK - 1, gk_shift = __builtin_ctz(GK);
-                    // A fragment of a tile: 16 floats of W_out[v] plus, as a 17th k step, the bias of v on the
-                    // k = 0 lanes (against b = 1): one dword per lane instead of a 64-B broadcast bias read.
-                    struct AFrag { float w[16]; float bias; };
+                    // A fragment of a tile.
+                    // fp32:  16 floats of W_out[v] plus, as a 17th k step, the bias of v on the k = 0 lanes (against
+                    //        b = 1): one dword per lane instead of a 64-B broadcast bias read.
+                    // split: four 16-B pieces (hi, lo halves of this lane's 16 scaled weights, two k blocks each) and a
+                    //        fifth holding the scaled bias as three bf16 parts (exact fp32), from the fragment-major
+                    //        copy made by k_gen_make_frag: every load instruction of a wave reads 1 KiB contiguous.
+                    struct AFrag { f32x4 w[4]; f32x4 bias; };
                     const float bone = hh ? 0.f : 1.f;
-                    float hb2[16];
+                    bf16x8 bone16;
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) hb2[j] = hb[j] * kL2E;
+                    for (int e = 0; e < 8; ++e) bone16[e] = (__bf16)((hh == 0 && e < 3) ? 1.f : 0.f);
+                    float inv = 1.f;
+                    if constexpr (SPLIT) inv = a.gscale[2];
+                    float hb2[16];
+                    f16x8 hbh[4];  // split: (hi k0-7, hi k8-15, lo k0-7, lo k8-15) of h * log2(e) * 2^13
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) {
+                        hb2[j] = hb[j] * kL2E;
+                        if constexpr (SPLIT) {
+                            const float x = hb2[j] * kGenHScale;
+                            const _Float16 xh = (_Float16)x;
+                            hbh[j >> 3][j & 7] = xh;
+                            hbh[2 + (j >> 3)][j & 7] = (_Float16)(x - (float)xh);
+                        }
+                    }
                     auto load_a = [&](int q, AFrag& dst) {
-                        const int v = a_sp * Ls + 16 * q + a_r;
-                        load16(a.w.w_out + (size_t)tg_min(v, V - 1) * kH + 16 * hh, dst.w);
-                        dst.bias = hh ? 0.f : (v < V ? a.w.b_out[v] * kL2E : TG_NEG_BIG);
+                        if constexpr (SPLIT) {
+                            const f32x4* p = a.frag + ((size_t)(w * NT + q) * 5) * 64 + lane;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dst.w[i] = p[i * 64];
+                            dst.bias = p[4 * 64];
+                        } else {
+                            const int v = a_sp * Ls + 16 * q + a_r;
+                            const f32x4* p = reinterpret_cast<const f32x4*>(a.w.w_out + (size_t)tg_min(v, V - 1) * kH + 16 * hh);
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) dst.w[i] = p[i];
+                            dst.bias[0] = hh ? 0.f : (v < V ? a.w.b_out[v] * kL2E : TG_NEG_BIG);
+                        }
                     };
                     auto mfma_tile = [&](int q, const AFrag& af) {
                         f32x16 acc;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        if constexpr (SPLIT) {
+                            // small terms first: lo.hi, hi.lo, hi.hi, then the bias (fp32 accumulation throughout)
+                            acc = TG_MFMA16(__builtin_bit_cast(f16x8, af.w[2]), hbh[0], acc);
+                            acc = TG_MFMA16(__builtin_bit_cast(f16x8, af.w[3]), hbh[1], acc);
+                            acc = TG_MFMA16(__builtin_bit_cast(f16x8, af.w[0]), hbh[2], acc);
+                            acc = TG_MFMA16(__builtin_bit_cast(f16x8, af.w[1]), hbh[3], acc);
+                            acc = TG_MFMA16(__builtin_bit_cast(f16x8, af.w[0]), hbh[0], acc);
+                            acc = TG_MFMA16(__builtin_bit_cast(f16x8, af.w[1]), hbh[1], acc);
+                            acc = TG_MFMA16BF(__builtin_bit_cast(bf16x8, af.bias), bone16, acc);
+                        } else {
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) acc = TG_MFMA32(af.w[j], hb2[j], acc);
-                        acc = TG_MFMA32(af.bias, bone, acc);
+                            for (int j = 0; j < 16; ++j) acc = TG_MFMA32(af.w[j >> 2][j & 3], hb2[j], acc);
+                            acc = TG_MFMA32(af.bias[0], bone, acc);
+                        }
                         return acc;
                     };
                     auto softmax_tile = [&](const f32x16& acc, int q) {
                         float tmax = acc[0];
 #pragma unroll
                         for (int r = 1; r < 16; ++r) tmax = __builtin_fmaxf(tmax, acc[r]);
+                        if constexpr (SPLIT) tmax *= inv;  // accumulators are in scaled units; inv is a power of two
                         const float m_new = __builtin_fmaxf(m_run, tmax);
                         // branch-free group restart (a select on the scalar condition would split the block
                         // and serialise the MFMA chain ahead of this VALU work)
@@ -439,7 +490,9 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                         c_grp = c_grp * __builtin_amdgcn_exp2f(m_run - m_new) * keep;
                         float ev[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(acc[r] - m_new);
+                        for (int r = 0; r < 16; ++r)
+                            ev[r] = SPLIT ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], inv, -m_new))  // one rounding
+                                          : __builtin_amdgcn_exp2f(acc[r] - m_new);
                         float ts = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) ts += ev[r];  // canonical order: sequential
@@ -448,13 +501,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                         // stored after every tile: the group's last tile leaves the final value
                         if (SAMPLE) rec[((q >> gk_shift) * kNSpan + sp) * kRows + n] = make_float2(m_run, c_grp);
                     };
-                    // ask the scheduler for 1 MFMA : 6 VALU in program order (the in-order wave otherwise parks
-                    // on the dependent MFMA chain with the softmax work queued behind it)
+                    // ask the scheduler for MFMA and VALU alternating in program order (the in-order wave otherwise
+                    // parks on the dependent MFMA chain with the softmax work queued behind it)
                     auto interleave = [&]() {
+                        if constexpr (SPLIT) {
 #pragma unroll
-                        for (int i = 0; i < 17; ++i) {
-                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
-                            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+                            for (int i = 0; i < 7; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0); // VALU
+                            }
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 17; ++i) {
+                                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+                                __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+                            }
                         }
                     };
                     if (nfull > 0) {
@@ -660,6 +721,82 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     }
 }
 
+// ---- split-fp16 projection: per-call preparation (the weights are live module parameters)
+__global__ __launch_bounds__(256) void k_gen_absmax(const float* x, size_t n, unsigned* out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);  // |x| as ordered bits
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
+__device__ __forceinline__ unsigned short tg_bf16_rn(float x) {  // round to nearest even; x finite
+    const unsigned u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+
+// W_out / b_out -> the A fragments of the split projection, in the order k_gen's waves load them:
+// piece ((w*NT + q)*5 + i)*64 + lane, 16 B each.  Lane (am, hh) of wave w owns vocab row
+// v = (2w + ((am>>2)&1))*Ls + 16q + (am&3) + 4(am>>3) (so that every D lane ends up with 16 consecutive entries of
+// its span) and the k range [16hh, 16hh+16):
+//   i = 0,1  fp16 hi of W_out[v][k]*sW, k blocks [0,8) and [8,16) of the lane's range
+//   i = 2,3  fp16 lo (the residual) of the same
+//   i = 4    lanes hh = 0: b_out[v]*log2(e)*sW*sH as three bf16 parts (sums back to the fp32 value exactly), or
+//            TG_NEG_BIG past the vocabulary's end; lanes hh = 1: zeros.
+// sW = power of two that puts max|W_out| in [2^13, 2^14); sH = 2^13.  Block (0,0) also publishes the scales.
+__global__ __launch_bounds__(64) void k_gen_make_frag(const float* __restrict__ w_out, const float* __restrict__ b_out,
+                                                      int V, int Ls, int NT, const unsigned* absmax, float* gscale,
+                                                      f32x4* frag) {
+    const int q = blockIdx.x, w = blockIdx.y, lane = threadIdx.x;
+    const float m = __uint_as_float(*absmax);
+    float sW = 1.f;
+    if (m > 0.f && m < __builtin_inff()) {
+        int ex = 0;
+        (void)frexpf(m, &ex);       // m < 2^ex
+        sW = ldexpf(1.f, 14 - ex);  // m*sW in [2^13, 2^14)
+    }
+    if (q == 0 && w == 0 && lane == 0) {
+        gscale[0] = sW;
+        gscale[1] = kGenHScale;
+        gscale[2] = 1.f / (sW * kGenHScale);
+    }
+    const int am = lane & 31, hh = lane >> 5;
+    const int v = (2 * w + ((am >> 2) & 1)) * Ls + 16 * q + (am & 3) + 4 * (am >> 3);
+    const float* row = w_out + (size_t)tg_min(v, V - 1) * 32 + 16 * hh;
+    f16x8 hi[2], lo[2];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float x = row[j] * sW;
+        const _Float16 xh = (_Float16)x;
+        hi[j >> 3][j & 7] = xh;
+        lo[j >> 3][j & 7] = (_Float16)(x - (float)xh);
+    }
+    f32x4* dst = frag + ((size_t)(w * NT + q) * 5) * 64 + lane;
+    dst[0] = __builtin_bit_cast(f32x4, hi[0]);
+    dst[64] = __builtin_bit_cast(f32x4, hi[1]);
+    dst[128] = __builtin_bit_cast(f32x4, lo[0]);
+    dst[192] = __builtin_bit_cast(f32x4, lo[1]);
+    unsigned p01 = 0, p2 = 0;
+    if (hh == 0) {
+        const float kL2E = 1.44269502162933349609375f;
+        const float x = (v < V) ? (b_out[v] * kL2E) * (sW * kGenHScale) : TG_NEG_BIG;
+        const unsigned short b0 = tg_bf16_rn(x);
+        const float r1 = x - __uint_as_float((unsigned)b0 << 16);
+        const unsigned short b1 = tg_bf16_rn(r1);
+        const float r2 = r1 - __uint_as_float((unsigned)b1 << 16);
+        const unsigned short b2 = tg_bf16_rn(r2);
+        p01 = (unsigned)b0 | ((unsigned)b1 << 16);
+        p2 = (unsigned)b2;
+    }
+    f32x4 bias;
+    bias[0] = __uint_as_float(p01);
+    bias[1] = __uint_as_float(p2);
+    bias[2] = 0.f;
+    bias[3] = 0.f;
+    dst[256] = bias;
+}
+
 SamplerGeom make_geom(int V) {
     SamplerGeom g;
     g.Ls = 16 * ((V + kNSpan * 16 - 1) / (kNSpan * 16));
@@ -671,6 +808,31 @@ SamplerGeom make_geom(int V) {
 }
 
 bool is_reg(int E, int H) { return E == 32 && H == 32; }
+
+// TG_GEN_SPLIT_F16 applies to the sampling kernel of the E = H = 32 shape; everything else computes in fp32
+bool use_split(const TgGenWeights& w) { return w.precision == TG_GEN_SPLIT_F16 && is_reg(w.E, w.H); }
+
+// bytes of the split-projection scratch: 256-B header (|max| bits, scales) + fragments
+size_t split_bytes(const SamplerGeom& g) { return 256 + (size_t)4 * g.NT * 5 * 64 * sizeof(f32x4); }
+
+// Fills the scratch (absmax -> scales -> fragments) on `stream` and points the kernel arguments at it.
+int prepare_split(GenArgs& a, void* scratch, hipStream_t stream) {
+    unsigned* absmax = reinterpret_cast<unsigned*>(scratch);
+    float* gscale = reinterpret_cast<float*>(reinterpret_cast<char*>(scratch) + 16);
+    f32x4* frag = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(scratch) + 256);
+    if (hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
+        tg_set_error("hipMemsetAsync failed");
+        return TG_ERR_LAUNCH;
+    }
+    const size_t n = (size_t)a.w.V * 32;
+    const int blocks = (int)((n + 1023) / 1024);
+    hipLaunchKernelGGL(k_gen_absmax, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, stream, a.w.w_out, n, absmax);
+    hipLaunchKernelGGL(k_gen_make_frag, dim3(a.geo.NT, 4), dim3(64), 0, stream, a.w.w_out, a.w.b_out, a.w.V, a.geo.Ls,
+                       a.geo.NT, absmax, gscale, frag);
+    a.frag = frag;
+    a.gscale = gscale;
+    return TG_OK;
+}
 
 size_t smem_bytes(const SamplerGeom& g, bool sample, int E, int H) {
     size_t b = sizeof(float) * kRows * (H + 4) + sizeof(float) * kNSpan * kRows + sizeof(double) * kNSpan * kRows +
@@ -700,7 +862,7 @@ int check_weights(const TgGenWeights* w) {
     return TG_OK;
 }
 
-template <bool SAMPLE, int HT, bool REG>
+template <bool SAMPLE, int HT, bool REG, bool SPLIT = false>
 int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
     size_t sm = smem_bytes(a.geo, SAMPLE, a.w.E, a.w.H);
     if (sm > 160 * 1024) {
@@ -710,7 +872,7 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
     }
     static thread_local size_t set_max = 0;
     if (sm > 48 * 1024 && sm > set_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG, SPLIT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -719,7 +881,7 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
         set_max = sm;
     }
     tg_prof_begin(SAMPLE ? TG_KERNEL_GEN_SAMPLE : TG_KERNEL_GEN_TEACHER, stream);
-    hipLaunchKernelGGL((k_gen<SAMPLE, HT, REG>), dim3(grid), dim3(kThreads), sm, stream, a);
+    hipLaunchKernelGGL((k_gen<SAMPLE, HT, REG, SPLIT>), dim3(grid), dim3(kThreads), sm, stream, a);
     tg_prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -731,6 +893,9 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
 
 template <bool SAMPLE>
 int launch(const GenArgs& a, int grid, hipStream_t stream) {
+    if constexpr (SAMPLE) {
+        if (a.frag) return launch_t<true, 1, true, true>(a, grid, stream);
+    }
     if (is_reg(a.w.E, a.w.H)) return launch_t<SAMPLE, 1, true>(a, grid, stream);
     switch (a.w.H) {
         case 32: return launch_t<SAMPLE, 1, false>(a, grid, stream);
@@ -774,8 +939,17 @@ extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, 
     return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
 }
 
-extern "C" size_t tg_gen_rollout_workspace_bytes(int B, int L, int H) {
-    return sizeof(float) * (size_t)(L + 1) * B * 2 * H;
+static size_t states_bytes(int B, int L, int H) {
+    return (sizeof(float) * (size_t)(L + 1) * B * 2 * H + 255) / 256 * 256;
+}
+
+extern "C" size_t tg_gen_rollout_workspace_bytes(const TgGenWeights* w, int B, int L) {
+    if (!w || B < 1 || L < 1) return 0;
+    return states_bytes(B, L, w->H) + (use_split(*w) ? split_bytes(make_geom(w->V)) : 0);
+}
+
+extern "C" size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w) {
+    return (w && use_split(*w)) ? split_bytes(make_geom(w->V)) : 0;
 }
 
 extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int L, int R, int g_lo, int g_hi,
@@ -790,9 +964,9 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
         return TG_ERR_ARG;
     }
     if (i_lo == i_hi) return TG_OK;
-    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(B, L, w->H)) {
+    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(w, B, L)) {
         tg_set_error("tg_gen_rollout: workspace too small (%zu < %zu)", workspace_bytes,
-                     tg_gen_rollout_workspace_bytes(B, L, w->H));
+                     tg_gen_rollout_workspace_bytes(w, B, L));
         return TG_ERR_WORKSPACE;
     }
     // 1) prefix states: teacher-forced pass over the sentences, no projection (rollout.py:35-38)
@@ -821,11 +995,16 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
         tg_set_error("tg_gen_rollout: grid too large");
         return TG_ERR_ARG;
     }
+    if (use_split(*w)) {
+        rc = prepare_split(a, reinterpret_cast<char*>(workspace) + states_bytes(B, L, w->H), (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return launch<true>(a, (int)grid, (hipStream_t)stream);
 }
 
 extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter, const float* uniforms,
-                             const int64_t* forced, int64_t* out, void* stream) {
+                             const int64_t* forced, int64_t* out, void* workspace, size_t workspace_bytes,
+                             void* stream) {
     int rc = check_weights(w);
     if (rc) return rc;
     if (!uniforms || !out || N < 0 || L < 1 || start_letter < 0 || start_letter >= w->V) {
@@ -843,5 +1022,14 @@ extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_
     a.rollout = 0;
     a.N = N;
     a.L = L;
+    if (use_split(*w)) {
+        if (!workspace || workspace_bytes < tg_gen_sample_workspace_bytes(w)) {
+            tg_set_error("tg_gen_sample: workspace too small (%zu < %zu)", workspace_bytes,
+                         tg_gen_sample_workspace_bytes(w));
+            return TG_ERR_WORKSPACE;
+        }
+        rc = prepare_split(a, workspace, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return launch<true>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
 }

@@ -36,10 +36,11 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 
-def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_lo=0, i_hi=None, out=None):
+def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_lo=0, i_hi=None, out=None,
+                precision=None):
     """tg_gen_rollout: every rollout_mc_search(sentences, g) of get_reward's loops
     (utils/rollout.py:25-55,143-145).  uniforms [R,L,L,B]; returns completions [R,L,B,L] int64."""
-    w, keep = _lib.gen_weights(gen)
+    w, keep = _lib.gen_weights(gen, precision)
     s, _ = _tokens(sentences, "sentences")
     B, L = s.shape
     g_hi = L if g_hi is None else g_hi
@@ -48,7 +49,7 @@ def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_l
         raise RuntimeError("textgan_hip: uniforms must have R*L*L*B = %d elements, got %d"
                            % (R * L * L * B, uniforms.numel()))
     comp = out if out is not None else torch.empty(R, L, B, L, dtype=I64, device=s.device)
-    nbytes = _lib.lib().tg_gen_rollout_workspace_bytes(B, L, w.H)
+    nbytes = _lib.lib().tg_gen_rollout_workspace_bytes(C.byref(w), B, L)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
     f = None if forced is None else _tokens(forced, "forced")[0]
     _lib.check(_lib.lib().tg_gen_rollout(
@@ -58,16 +59,19 @@ def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_l
     return comp
 
 
-def gen_sample(gen, N, L, start_letter, uniforms, forced=None):
+def gen_sample(gen, N, L, start_letter, uniforms, forced=None, precision=None):
     """tg_gen_sample: the step loop of LSTMGenerator.sample (models/generator.py:71-81) for N rows.
     uniforms [L,N]; returns [N,L] int64 on the device."""
-    w, keep = _lib.gen_weights(gen)
+    w, keep = _lib.gen_weights(gen, precision)
     if uniforms.numel() != L * N:
         raise RuntimeError("textgan_hip: uniforms must have L*N = %d elements" % (L * N))
     out = torch.empty(N, L, dtype=I64, device=uniforms.device)
     f = None if forced is None else _tokens(forced, "forced")[0]
+    nbytes = _lib.lib().tg_gen_sample_workspace_bytes(C.byref(w))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=uniforms.device) if nbytes else None
     _lib.check(_lib.lib().tg_gen_sample(C.byref(w), N, L, int(start_letter), _lib.dev_ptr(uniforms, F32, "uniforms"),
-                                        _lib.dev_ptr(f, I64, "forced"), _lib.dev_ptr(out), _lib.stream_ptr()))
+                                        _lib.dev_ptr(f, I64, "forced"), _lib.dev_ptr(out), _lib.dev_ptr(ws), nbytes,
+                                        _lib.stream_ptr()))
     return out
 
 

@@ -19,6 +19,8 @@ class ROLLOUT:
     dis_chunk = 1 << 17
     #: conv arithmetic of the scorer: None = library default ("split_f16"), or "fp32" (see TG_DIS_*)
     dis_precision = None
+    #: arithmetic of the generator's vocabulary projection: None = library default, "fp32" or "split_f16" (TG_GEN_*)
+    gen_precision = None
 
     def __init__(self, gen, gpu=True):
         self.gen = gen
@@ -62,7 +64,8 @@ class ROLLOUT:
             raise RuntimeError("given_num must be in [1, %d]" % L)
         with torch.no_grad():
             u = uniforms if uniforms is not None else self._rand((1, L, L, B), sentences.device)
-            comp = ops.gen_rollout(self.gen, sentences, 1, u, g_lo=given_num, g_hi=given_num)
+            comp = ops.gen_rollout(self.gen, sentences, 1, u, g_lo=given_num, g_hi=given_num,
+                                   precision=self.gen_precision)
         return comp[0, given_num - 1]
 
     def get_reward(self, sentences, rollout_num, dis, current_k=0, uniforms=None, dropout_uniforms=None,
@@ -88,7 +91,7 @@ class ROLLOUT:
             comp = None
             if Rl > 0:
                 with self._timed("gen_rollout"):
-                    comp = ops.gen_rollout(self.gen, sentences, Rl, u)
+                    comp = ops.gen_rollout(self.gen, sentences, Rl, u, precision=self.gen_precision)
                 p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
                 weights = _lib.dis_weights(dis, self.dis_precision)
                 F = weights[0].F
