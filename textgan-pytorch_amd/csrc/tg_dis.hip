@@ -12,6 +12,8 @@
 // Embedding dim Ed = 64 (config.py:113 of the reference) is compiled in.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "tg_common.h"
 
 namespace {
@@ -126,20 +128,15 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         const int K = f * kEd, T = L - f + 1;
         const int arow = tg_min(mt * 32 + n, nk - 1);
         const float* wp = a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
-        const _Float16* wph = SPLIT ? a.w16 + a.woff[k] + (size_t)arow * K + 8 * hh : nullptr;
-        const size_t wlo_off = (size_t)nk * K;
         const int ntile = (T + TT - 1) >> (5 - log2S);  // ceil(T / TT)
 
         float runmax[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) runmax[r] = TG_NEG_INF;
 
-        // windows t <= g - f lie inside the shared prefix: start at the first tile with a fresh window
-        const int nb_start = (MODE == kConvPrefix) ? (tg_max(0, g_min - f + 1) >> (5 - log2S)) : 0;
-        for (int nb0 = nb_start; nb0 < ntile; nb0 += 4) {
-            const int nbc = tg_min(4, ntile - nb0);
-            f32x16 acc[4];
-            int boff[4];
+        f32x16 acc[4];
+        int boff[4];
+        auto start_chunk = [&](int nb0) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
@@ -147,53 +144,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 const int t = tg_min((nb0 + nt) * TT + tsub, T - 1);
                 boff[nt] = SPLIT ? (t * S + s) * kERowH + 8 * hh : (t * S + s) * kERow + 32 * hh;
             }
-            if (SPLIT) {
-                for (int tau = 0; tau < f; ++tau) {
-                    f16x8 ah[4], al[4];
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        ah[ks] = *reinterpret_cast<const f16x8*>(wph + tau * kEd + 16 * ks);
-                        al[ks] = *reinterpret_cast<const f16x8*>(wph + wlo_off + tau * kEd + 16 * ks);
-                    }
-                    const int toff = tau * S * kERowH;
-#pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-#pragma unroll
-                        for (int nt = 0; nt < 4; ++nt) {
-                            if (nt < nbc) {
-                                const f16x8 bh = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + 16 * ks);
-                                const f16x8 bl = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + kEd + 16 * ks);
-                                acc[nt] = TG_MFMA16(ah[ks], bh, acc[nt]);
-                                acc[nt] = TG_MFMA16(ah[ks], bl, acc[nt]);
-                                acc[nt] = TG_MFMA16(al[ks], bh, acc[nt]);
-                            }
-                        }
-                    }
-                }
-                const float inv = a.scales[2];
-#pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[nt][r] *= inv;
-            } else
-            for (int tau = 0; tau < f; ++tau) {
-                f32x4 av[8];
-                const f32x4* pa = reinterpret_cast<const f32x4*>(wp + tau * kEd);
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) av[jj] = pa[jj];
-                const int toff = tau * S * kERow;
-#pragma unroll
-                for (int jj = 0; jj < 8; ++jj) {
-#pragma unroll
-                    for (int nt = 0; nt < 4; ++nt) {
-                        if (nt < nbc) {
-                            const f32x4 bv = *reinterpret_cast<const f32x4*>(ebuf + boff[nt] + toff + 4 * jj);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) acc[nt] = TG_MFMA32(av[jj][e], bv[e], acc[nt]);
-                        }
-                    }
-                }
-            }
+        };
+        auto finish_chunk = [&](int nb0, int nbc) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int tw = (nb0 + nt) * TT + tsub;
@@ -214,6 +166,99 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], ok ? acc[nt][r] : TG_NEG_INF);
                 }
+            }
+        };
+
+        // windows t <= g - f lie inside the shared prefix: start at the first tile with a fresh window
+        const int nb_start = (MODE == kConvPrefix) ? (tg_max(0, g_min - f + 1) >> (5 - log2S)) : 0;
+        if constexpr (SPLIT) {
+            // A fragments of (k, mt) in load order (k_split_weights): [tau][8 pieces][64 lanes] x 16 B, pieces 0-3 the
+            // hi halves of k blocks 0-3, pieces 4-7 their lo halves.  One flat loop over (chunk of 4 N-tiles, tau)
+            // with the next stage's fragment in flight in a second register set.
+            const f16x8* wfrag = reinterpret_cast<const f16x8*>(a.w16 + a.woff[k]) + ((size_t)mt * f * 8) * 64 + lane;
+            const float inv = a.scales[2];
+            const int total = ((ntile - nb_start + 3) >> 2) * f;
+            int tau = 0, nb0 = nb_start;
+            f16x8 A0[8], A1[8];
+            auto load_a = [&](f16x8 (&A)[8], int ta) {
+                const f16x8* pa = wfrag + (size_t)ta * 8 * 64;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) A[i] = pa[i * 64];
+            };
+            // the MFMA block of one stage for a compile-time tile count: straight-line code, so the LDS reads of later
+            // tiles are issued under the MFMAs of earlier ones (a run-time "nt < nbc" guard puts every tile in a basic
+            // block of its own, each waiting out its LDS latency)
+            auto mfma_block = [&](const f16x8 (&cur)[8], int toff, auto nbc_tag) {
+                constexpr int NBC = decltype(nbc_tag)::value;
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+                    for (int nt = 0; nt < NBC; ++nt) {
+                        const f16x8 bh = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + 16 * ks);
+                        const f16x8 bl = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + kEd + 16 * ks);
+                        acc[nt] = TG_MFMA16(cur[ks], bh, acc[nt]);
+                        acc[nt] = TG_MFMA16(cur[ks], bl, acc[nt]);
+                        acc[nt] = TG_MFMA16(cur[4 + ks], bh, acc[nt]);
+                    }
+                }
+            };
+            auto stage = [&](const f16x8 (&cur)[8], f16x8 (&nxt)[8], bool more) {
+                const int nbc = tg_min(4, ntile - nb0);
+                if (tau == 0) start_chunk(nb0);
+                const int tau_n = (tau + 1 == f) ? 0 : tau + 1;
+                if (more) load_a(nxt, tau_n);
+                const int toff = tau * S * kERowH;
+                switch (nbc) {
+                    case 4: mfma_block(cur, toff, std::integral_constant<int, 4>{}); break;
+                    case 3: mfma_block(cur, toff, std::integral_constant<int, 3>{}); break;
+                    case 2: mfma_block(cur, toff, std::integral_constant<int, 2>{}); break;
+                    default: mfma_block(cur, toff, std::integral_constant<int, 1>{}); break;
+                }
+                if (tau_n == 0) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[nt][r] *= inv;
+                    finish_chunk(nb0, nbc);
+                    nb0 += 4;
+                }
+                tau = tau_n;
+            };
+            if (total > 0) load_a(A0, 0);
+            for (int it = 0; it < total; it += 2) {
+                stage(A0, A1, it + 1 < total);
+                if (it + 1 < total) stage(A1, A0, it + 2 < total);
+            }
+        } else {
+            for (int nb0 = nb_start; nb0 < ntile; nb0 += 4) {
+                const int nbc = tg_min(4, ntile - nb0);
+                start_chunk(nb0);
+                auto mfma_block = [&](const f32x4 (&av)[8], int toff, auto nbc_tag) {
+                    constexpr int NBC = decltype(nbc_tag)::value;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+#pragma unroll
+                        for (int nt = 0; nt < NBC; ++nt) {
+                            const f32x4 bv = *reinterpret_cast<const f32x4*>(ebuf + boff[nt] + toff + 4 * jj);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[nt] = TG_MFMA32(av[jj][e], bv[e], acc[nt]);
+                        }
+                    }
+                };
+                for (int tau = 0; tau < f; ++tau) {
+                    f32x4 av[8];
+                    const f32x4* pa = reinterpret_cast<const f32x4*>(wp + tau * kEd);
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) av[jj] = pa[jj];
+                    const int toff = tau * S * kERow;
+                    switch (nbc) {
+                        case 4: mfma_block(av, toff, std::integral_constant<int, 4>{}); break;
+                        case 3: mfma_block(av, toff, std::integral_constant<int, 3>{}); break;
+                        case 2: mfma_block(av, toff, std::integral_constant<int, 2>{}); break;
+                        default: mfma_block(av, toff, std::integral_constant<int, 1>{}); break;
+                    }
+                }
+                finish_chunk(nb0, nbc);
             }
         }
         if (MODE == kConvStoreAll) continue;
@@ -285,23 +330,37 @@ __global__ void k_make_scales(const unsigned* absmax, float* scales) {
 
 struct SplitArgs {
     const float* src[TG_MAX_FILTERS];
-    int woff[TG_MAX_FILTERS];
-    int count[TG_MAX_FILTERS];  // n_k * f_k * 64
+    int woff[TG_MAX_FILTERS];   // halves
+    int nk[TG_MAX_FILTERS];
+    int f[TG_MAX_FILTERS];
     int n_filters;
     _Float16* w16;
     const float* scales;
 };
 
+// Conv weights -> scaled (hi, lo) fp16 halves in the order k_dis_conv<.., SPLIT> loads them: bank k, 32-filter tile
+// mt, window row tau, piece p (0-3 hi / 4-7 lo of the k block p&3), lane: 8 halves
+// W[min(mt*32 + (lane&31), n_k-1)][tau*64 + 16*(p&3) + 8*(lane>>5) + 0..7] -- one 16-B store per thread, and every
+// load instruction of a wave reads 1 KiB contiguous.
 __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
     const int k = blockIdx.y;
     const float sc = a.scales[0];
-    _Float16* hi = a.w16 + a.woff[k];
-    _Float16* lo = hi + a.count[k];
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < a.count[k]; i += gridDim.x * 256) {
-        const float x = a.src[k][i] * sc;
-        const _Float16 h = (_Float16)x;
-        hi[i] = h;
-        lo[i] = (_Float16)(x - (float)h);
+    const int f = a.f[k], nk = a.nk[k], K = f * kEd;
+    const int total = ((nk + 31) / 32) * f * 8 * 64;
+    f16x8* dst = reinterpret_cast<f16x8*>(a.w16 + a.woff[k]);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int lane = i & 63, p = (i >> 6) & 7, mtau = i >> 9;
+        const int tau = mtau % f, mt = mtau / f;
+        const int row = tg_min(mt * 32 + (lane & 31), nk - 1);
+        const float* src = a.src[k] + (size_t)row * K + tau * kEd + 16 * (p & 3) + 8 * (lane >> 5);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = src[e] * sc;
+            const _Float16 h = (_Float16)x;
+            o[e] = (p < 4) ? h : (_Float16)(x - (float)h);
+        }
+        dst[i] = o;
     }
 }
 
@@ -490,18 +549,27 @@ __device__ __forceinline__ void hs_commit(const HsStage& st, _Float16* dst, int 
 
 __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_dis_highway_split(const HsArgs a) {
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[kHwTile * kHsStride];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[kHwTile * kHsStride];
-    __shared__ __attribute__((aligned(16))) _Float16 Bh[kHwTile * kHsStride];
-    __shared__ __attribute__((aligned(16))) _Float16 Bl[kHwTile * kHsStride];
-    __shared__ float red[2][kHwTile][kMaxOut];
+    // 4 operand tiles of 18 KiB; the epilogue's cross-wave partials reuse the first one, so that two workgroups
+    // (two waves per SIMD) fit a CU's 160 KiB: one's barrier waits run under the other's MFMAs
+    __shared__ __attribute__((aligned(16))) _Float16 tiles[4 * kHwTile * kHsStride];
+    _Float16* Ah = tiles;
+    _Float16* Al = tiles + kHwTile * kHsStride;
+    _Float16* Bh = tiles + 2 * kHwTile * kHsStride;
+    _Float16* Bl = tiles + 3 * kHwTile * kHsStride;
+    static_assert(sizeof(float) * 2 * kHwTile * kMaxOut <= sizeof(_Float16) * kHwTile * kHsStride, "red must fit a tile");
+    float (*red)[kHwTile][kMaxOut] = reinterpret_cast<float (*)[kHwTile][kMaxOut]>(tiles);
 
     const int F = a.h.w.F;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;
     const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
-    const int bn = blockIdx.x % a.h.nchunk, bm = blockIdx.x / a.h.nchunk;
+    // Workgroups go to the 8 XCDs round-robin by blockIdx.  XCD x takes the sequence tiles bm = x (mod 8) and walks
+    // all feature chunks of one tile before the next, so the workgroups resident on an XCD together share their
+    // pooled tile 14 ways and the W_hw slabs ~4 ways inside that XCD's L2 (the operands, 371 MB, do not fit it).
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int bn = jx % a.h.nchunk, bm = (jx / a.h.nchunk) * 8 + xcd;
+    if (bm >= a.h.nseqtile) return;
     const int f0 = bn * kHwTile, s0 = bm * kHwTile;
     const size_t wlo = (size_t)F * F, plo = (size_t)a.h.N * F;
 
@@ -560,6 +628,7 @@ void k_dis_highway_split(const HsArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
+    __syncthreads();  // the last tile's reads are done before red overwrites it
     hw_epilogue(a.h, acc, red, f0, s0, bn, wm, wn, n, hh, tid);
 }
 
@@ -784,9 +853,12 @@ int launch_conv(const ConvArgs& ca, size_t sm, hipStream_t stream) {
     return ca.w16 ? launch_conv_t<MODE, true>(ca, sm, stream) : launch_conv_t<MODE, false>(ca, sm, stream);
 }
 
-size_t conv_weight_count(const TgDisWeights* w) {
+// fp16 halves of one bank in fragment order (hi and lo, filter count padded to a multiple of 32)
+size_t conv_frag_halves(const TgDisWeights* w, int k) { return (size_t)((w->n[k] + 31) / 32) * w->f[k] * 8 * 64 * 8; }
+
+size_t conv_weight_count(const TgDisWeights* w) {  // (hi, lo) pairs
     size_t n = 0;
-    for (int k = 0; k < w->n_filters; ++k) n += (size_t)w->n[k] * w->f[k] * kEd;
+    for (int k = 0; k < w->n_filters; ++k) n += conv_frag_halves(w, k) / 2;
     return n;
 }
 
@@ -816,10 +888,12 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
                            (size_t)cnt, absmax);
         sa.src[k] = w->conv_w[k];
         sa.woff[k] = off;
-        sa.count[k] = cnt;
+        sa.nk[k] = w->n[k];
+        sa.f[k] = w->f[k];
         ca.woff[k] = off;
-        off += 2 * cnt;
-        maxcount = cnt > maxcount ? cnt : maxcount;
+        const int pieces = (int)(conv_frag_halves(w, k) / 8);
+        off += pieces * 8;
+        maxcount = pieces > maxcount ? pieces : maxcount;
     }
     const size_t ne = (size_t)w->V * kEd;
     hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 512)), dim3(256), 0, stream, w->emb, ne,
@@ -942,7 +1016,8 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         hs.p_hi = p16;
         hs.scales = scales;
         tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
-        hipLaunchKernelGGL(k_dis_highway_split, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, hs);
+        hipLaunchKernelGGL(k_dis_highway_split, dim3(8 * ((ha.nseqtile + 7) / 8) * nchunk), dim3(kHwThreads), 0, stream,
+                           hs);
         tg_prof_end(stream);
     } else {
         tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);

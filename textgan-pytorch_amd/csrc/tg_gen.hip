@@ -603,10 +603,16 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             // the running max of a span settles early: consecutive records mostly share their scale factor
             double s = 0.0, fac = 1.0;
             float fx = M;
-            for (int q = 0; q < ng_valid; ++q) {
-                const float2 r = rec[(q * kNSpan + sp) * kRows + n];
-                if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
-                s += (double)r.y * fac;
+            float2 rq[16];  // NG <= 16: all reads in flight before the (sequential, fp64) sum starts
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rq[q] = rec[(tg_min(q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                if (q < ng_valid) {
+                    const float2 r = rq[q];
+                    if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
+                    s += (double)r.y * fac;
+                }
             }
             sbuf[sp * kRows + n] = s;
         }
@@ -628,12 +634,19 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                 int gq = ng_valid - 1;
                 double fac = 1.0;
                 float fx = M;
-                for (int q = 0; q < ng_valid; ++q) {
-                    const float2 r = rec[(q * kNSpan + sp) * kRows + n];
-                    if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
-                    const double c = (double)r.y * fac;
-                    if (p + c > target || q == ng_valid - 1) { gq = q; break; }
-                    p += c;
+                float2 rq[16];
+#pragma unroll
+                for (int q = 0; q < 16; ++q) rq[q] = rec[(tg_min(q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
+                bool found = false;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    if (q < ng_valid && !found) {
+                        const float2 r = rq[q];
+                        if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
+                        const double c = (double)r.y * fac;
+                        if (p + c > target || q == ng_valid - 1) { gq = q; found = true; }
+                        else p += c;
+                    }
                 }
                 selv[n] = sp_lo + gq * EG;
                 selp[n] = p;
@@ -645,7 +658,47 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         const long long d2 = clock64();
         // cooperative recompute of the chosen groups: 8 threads per row, each EG/8 entries of that row with the
         // row's h held in registers (REG) or read from LDS per chunk
-        {
+        if constexpr (SPLIT) {
+            // The first pass ran on split-fp16 MFMAs, whose rounding a VALU chain cannot reproduce, so the recompute
+            // is free to pick its own summation order: thread (row, c) holds floats [4c, 4c+4) of the row's h and
+            // takes the same 16-B column slice of every W_out row of the group -- the 8 threads of a row read each
+            // 128-B weight row as one contiguous line -- and the 8 partial dots are summed across lanes (DPP).
+            const int rr = tid >> 3, c = tid & 7;
+            const int gv = selv[rr];
+            const int vend = tg_min(V, (gv / Ls + 1) * Ls);
+            const float Mr = Mbuf[rr];
+            f32x4 h4 = *reinterpret_cast<const f32x4*>(hbuf + rr * kHStride + 4 * c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h4[e] *= kL2E;
+            auto dpp_add = [](float x, auto ctrl) {
+                constexpr int C = decltype(ctrl)::value;
+                const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, 0xf, 0xf, true);
+                return x + __builtin_bit_cast(float, y);
+            };
+            for (int i0 = 0; i0 < EG; i0 += 8) {
+                f32x4 wv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    wv[i] = *reinterpret_cast<const f32x4*>(a.w.w_out + (size_t)tg_min(gv + i0 + i, V - 1) * kH + 4 * c);
+                float mine = 0.f;  // entry i0 + c ends up with this thread
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float p = wv[i][0] * h4[0];
+                    p = __builtin_fmaf(wv[i][1], h4[1], p);
+                    p = __builtin_fmaf(wv[i][2], h4[2], p);
+                    p = __builtin_fmaf(wv[i][3], h4[3], p);
+                    p = dpp_add(p, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]: lane ^ 1
+                    p = dpp_add(p, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]: lane ^ 2
+                    p = dpp_add(p, std::integral_constant<int, 0x141>{});  // row_half_mirror: the other quad of the 8
+                    mine = (i == c) ? p : mine;
+                }
+                const int e = i0 + c;
+                const int v = gv + e;
+                float wgt = 0.f;
+                if (v < vend) wgt = __builtin_amdgcn_exp2f((mine + a.w.b_out[v] * kL2E) - Mr);
+                wbuf[rr * (EG + 1) + e] = wgt;
+            }
+        } else {
             const int rr = tid >> 3, e0 = tid & 7;
             const int gv = selv[rr];
             const int vend = tg_min(V, (gv / Ls + 1) * Ls);
@@ -691,19 +744,29 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
             double p = selp[n];
             const float* wr = wbuf + n * (EG + 1);
             int tq = nt_valid - 1;
-            for (int tt = 0; tt < nt_valid; ++tt) {
-                float ts = 0.f;
-                for (int r = 0; r < 16; ++r) ts += wr[tt * 16 + r];  // entries >= vend are 0
-                if (p + (double)ts > target || tt == nt_valid - 1) { tq = tt; break; }
-                p += (double)ts;
+            bool found = false;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {  // GK <= 8; same arithmetic as a loop with an early exit
+                if (tt < nt_valid && !found) {
+                    float ts = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ts += wr[tt * 16 + r];  // entries >= vend are 0
+                    if (p + (double)ts > target || tt == nt_valid - 1) { tq = tt; found = true; }
+                    else p += (double)ts;
+                }
             }
             const int t_lo = gv + tq * 16;
             const int t_hi = tg_min(g_hi, t_lo + 16);
             int drawn = t_hi - 1;
+            float wt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wt[r] = wr[tq * 16 + r];
             float pp = 0.f;
-            for (int v = t_lo; v < t_hi; ++v) {
-                pp += wr[v - gv];
-                if (p + (double)pp > target) { drawn = v; break; }
+            bool hit = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pp += wt[r];
+                if (!hit && t_lo + r < t_hi && p + (double)pp > target) { drawn = t_lo + r; hit = true; }
             }
             if (valid) out_row[t] = drawn;
             tokbuf[n] = forced_row ? clamp_tok(forced_row[t], V) : drawn;
