@@ -49,6 +49,7 @@ struct ConvArgs {
     // its lo part n_k*f_k*64 halves later; scales = {scale_w, scale_e, 1/(scale_w*scale_e)} on the device
     const _Float16* w16;
     const float* scales;
+    unsigned* pooled_absmax;   // nullable: max of the pooled features as ordered bits (they are >= 0), for the highway's scale
     int woff[TG_MAX_FILTERS];
     ConvItem items[kMaxItems]; // sorted by cost, heaviest first
 };
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         g_min = __builtin_amdgcn_readfirstlane(g_min);
     }
 
+    float pmax = 0.f;  // largest pooled value this lane stored
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(ctr, 1);
@@ -287,6 +289,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                         for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(o[e], pv[e]);
                     }
                     *reinterpret_cast<f32x4*>(po + m0) = o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) pmax = __builtin_fmaxf(pmax, o[e]);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -294,10 +298,21 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                             float o = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
                             if (pm) o = __builtin_fmaxf(o, pm[m0 + e]);
                             po[m0 + e] = o;
+                            pmax = __builtin_fmaxf(pmax, o);
                         }
                 }
             }
         }
+    }
+    if (MODE != kConvStoreAll && a.pooled_absmax) {  // one atomic per workgroup
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) pmax = __builtin_fmaxf(pmax, __shfl_xor(pmax, off, 64));
+        __syncthreads();  // every wave is out of the item loop: the counter word is free
+        if (tid == 0) *ctr = 0;
+        __syncthreads();
+        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(ctr), __float_as_uint(pmax));
+        __syncthreads();
+        if (tid == 0 && *ctr) atomicMax(a.pooled_absmax, (unsigned)*ctr);
     }
 }
 
@@ -362,6 +377,16 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
         }
         dst[i] = o;
     }
+}
+
+__global__ __launch_bounds__(256) void k_absmax_banks(const SplitArgs a, unsigned* out) {
+    const int k = blockIdx.y, cnt = a.nk[k] * a.f[k] * kEd;
+    unsigned m = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256)
+        m = max(m, __float_as_uint(a.src[k][i]) & 0x7fffffffu);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 __global__ __launch_bounds__(256) void k_split(const float* src, size_t n, _Float16* hi, _Float16* lo,
@@ -463,7 +488,7 @@ __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     __shared__ __attribute__((aligned(16))) float Bs[kHwTile * kHwStride];  // pooled rows (sequences)
     __shared__ float red[2][kHwTile][kMaxOut];                              // cross-wave logit partials
 
-    const int F = a.w.F, n_out = a.w.n_out;
+    const int F = a.w.F;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv >> 1, wn = wv & 1;  // wave tile: features wm*64.., sequences wn*64..
@@ -519,13 +544,13 @@ __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     hw_epilogue(a, acc, red, f0, s0, bn, wm, wn, n, hh, tid);
 }
 
-// ---- highway GEMM on split-fp16 operands (both pre-split into (hi, lo) halves, see TG_DIS_SPLIT_F16)
+// ---- highway GEMM on split-fp16 operands (TG_DIS_SPLIT_F16): W_hw pre-split into (hi, lo) halves by k_split, the
+// pooled features split while they are staged into LDS (they are read as fp32 either way: no extra pass, no copy)
 constexpr int kHsBK = 64;              // halves per tile row
 constexpr int kHsStride = kHsBK + 8;   // 144-B rows: 9 16-B slots (odd) -> conflict-free ds_read_b128
 struct HsArgs {
     HwArgs h;
     const _Float16* w_hi;   // [F,F] scaled hw_w, lo part F*F halves later
-    const _Float16* p_hi;   // [N,F] scaled pooled, lo part N*F halves later
     const float* scales;    // {scale_w, scale_p, 1/(scale_w*scale_p)}
 };
 
@@ -545,6 +570,39 @@ __device__ __forceinline__ void hs_commit(const HsStage& st, _Float16* dst, int 
     const int c = tid & 7, r0 = tid >> 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(dst + (r0 + 32 * i) * kHsStride + 8 * c) = st.v[i];
+}
+// the fp32 operand (pooled): same tile shape, 8 floats per (row, chunk)
+struct HsStageF { f32x4 v[4][2]; };
+__device__ __forceinline__ void hs_fetch_f32(HsStageF& st, const float* src, int row0, int nrows, int k0, int F, int tid) {
+    const int c = tid & 7, r0 = tid >> 3;
+    const int k = k0 + 8 * c;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = tg_min(row0 + r0 + 32 * i, nrows - 1);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        st.v[i][0] = z;
+        st.v[i][1] = z;
+        if (k < F) {
+            const f32x4* p = reinterpret_cast<const f32x4*>(src + (size_t)row * F + k);
+            st.v[i][0] = p[0];
+            st.v[i][1] = p[1];
+        }
+    }
+}
+__device__ __forceinline__ void hs_commit_split(const HsStageF& st, _Float16* hi, _Float16* lo, float sc, int tid) {
+    const int c = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float x = st.v[i][e >> 2][e & 3] * sc;
+            h[e] = (_Float16)x;
+            l[e] = (_Float16)(x - (float)h[e]);
+        }
+        *reinterpret_cast<f16x8*>(hi + (r0 + 32 * i) * kHsStride + 8 * c) = h;
+        *reinterpret_cast<f16x8*>(lo + (r0 + 32 * i) * kHsStride + 8 * c) = l;
+    }
 }
 
 __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -571,7 +629,8 @@ void k_dis_highway_split(const HsArgs a) {
     const int bn = jx % a.h.nchunk, bm = (jx / a.h.nchunk) * 8 + xcd;
     if (bm >= a.h.nseqtile) return;
     const int f0 = bn * kHwTile, s0 = bm * kHwTile;
-    const size_t wlo = (size_t)F * F, plo = (size_t)a.h.N * F;
+    const size_t wlo = (size_t)F * F;
+    const float sp = a.scales[1];
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -581,23 +640,21 @@ void k_dis_highway_split(const HsArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    HsStage sah, sal, sbh, sbl;
+    HsStage sah, sal;
+    HsStageF sb;
     hs_fetch(sah, a.w_hi, f0, F, 0, F, tid);
     hs_fetch(sal, a.w_hi + wlo, f0, F, 0, F, tid);
-    hs_fetch(sbh, a.p_hi, s0, a.h.N, 0, F, tid);
-    hs_fetch(sbl, a.p_hi + plo, s0, a.h.N, 0, F, tid);
+    hs_fetch_f32(sb, a.h.pooled, s0, a.h.N, 0, F, tid);
     for (int k0 = 0; k0 < F; k0 += kHsBK) {
         __syncthreads();
         hs_commit(sah, Ah, tid);
         hs_commit(sal, Al, tid);
-        hs_commit(sbh, Bh, tid);
-        hs_commit(sbl, Bl, tid);
+        hs_commit_split(sb, Bh, Bl, sp, tid);
         __syncthreads();
         if (k0 + kHsBK < F) {
             hs_fetch(sah, a.w_hi, f0, F, k0 + kHsBK, F, tid);
             hs_fetch(sal, a.w_hi + wlo, f0, F, k0 + kHsBK, F, tid);
-            hs_fetch(sbh, a.p_hi, s0, a.h.N, k0 + kHsBK, F, tid);
-            hs_fetch(sbl, a.p_hi + plo, s0, a.h.N, k0 + kHsBK, F, tid);
+            hs_fetch_f32(sb, a.h.pooled, s0, a.h.N, k0 + kHsBK, F, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < kHsBK / 16; ++ks) {
@@ -867,7 +924,7 @@ size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
     return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut) +
            align256(sizeof(float) * (size_t)B_prefix * L * w->F) +
            align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256 +
-           align256(2 * sizeof(_Float16) * (size_t)N * w->F) + align256(2 * sizeof(_Float16) * (size_t)w->F * w->F);
+           align256(2 * sizeof(_Float16) * (size_t)w->F * w->F);
 }
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
@@ -881,11 +938,9 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     }
     tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
     SplitArgs sa = {};
-    int off = 0, maxcount = 0;
+    int off = 0, maxcount = 0, maxelems = 0;
     for (int k = 0; k < w->n_filters; ++k) {
         const int cnt = w->n[k] * w->f[k] * kEd;
-        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((cnt + 255) / 256, 256)), dim3(256), 0, stream, w->conv_w[k],
-                           (size_t)cnt, absmax);
         sa.src[k] = w->conv_w[k];
         sa.woff[k] = off;
         sa.nk[k] = w->n[k];
@@ -894,12 +949,15 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
         const int pieces = (int)(conv_frag_halves(w, k) / 8);
         off += pieces * 8;
         maxcount = pieces > maxcount ? pieces : maxcount;
+        maxelems = cnt > maxelems ? cnt : maxelems;
     }
+    sa.n_filters = w->n_filters;
+    hipLaunchKernelGGL(k_absmax_banks, dim3(tg_min_host((maxelems + 255) / 256, 64), w->n_filters), dim3(256), 0, stream,
+                       sa, absmax);
     const size_t ne = (size_t)w->V * kEd;
     hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 512)), dim3(256), 0, stream, w->emb, ne,
                        absmax + 1);
     hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
-    sa.n_filters = w->n_filters;
     sa.w16 = w16;
     sa.scales = scales;
     hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters), dim3(256), 0,
@@ -907,6 +965,7 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     tg_prof_end(stream);
     ca.w16 = w16;
     ca.scales = scales;
+    ca.pooled_absmax = absmax + 3;  // read by the highway's scale (score_impl)
     return TG_OK;
 }
 
@@ -941,8 +1000,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut));
     _Float16* w16 = (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
     void* scal = (char*)w16 + align256(2 * sizeof(_Float16) * conv_weight_count(w));
-    _Float16* p16 = (_Float16*)((char*)scal + 256);
-    _Float16* hw16 = (_Float16*)((char*)p16 + align256(2 * sizeof(_Float16) * (size_t)N * w->F));
+    _Float16* hw16 = (_Float16*)((char*)scal + 256);
 
     // ---- conv
     ConvArgs ca = {};
@@ -995,25 +1053,21 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     ha.nchunk = nchunk;
     ha.nseqtile = (N + kHwTile - 1) / kHwTile;
     if (w->precision == TG_DIS_SPLIT_F16 && (w->F & 7) == 0) {
-        // scales from |max| of hw_w and of the pooled features, then (hi, lo) halves of both operands
+        // scales from |max| of hw_w and of the pooled features (the conv kernels' epilogue left that one), then the
+        // (hi, lo) halves of hw_w
         unsigned* absmax = (unsigned*)scal + 2;
         float* scales = (float*)((char*)scal + 16) + 4;
-        const size_t nw = (size_t)w->F * w->F, np = (size_t)N * w->F;
+        const size_t nw = (size_t)w->F * w->F;
         tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
         hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 1024)), dim3(256), 0, stream, w->hw_w, nw,
                            absmax);
-        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((np / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
-                           pooled, np, absmax + 1);
         hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
         hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((nw / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
                            w->hw_w, nw, hw16, hw16 + nw, scales);
-        hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((np / 4 + 255) / 256) + 1, 4096)), dim3(256), 0, stream,
-                           (const float*)pooled, np, p16, p16 + np, scales + 1);
         tg_prof_end(stream);
         HsArgs hs = {};
         hs.h = ha;
         hs.w_hi = hw16;
-        hs.p_hi = p16;
         hs.scales = scales;
         tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
         hipLaunchKernelGGL(k_dis_highway_split, dim3(8 * ((ha.nseqtile + 7) / 8) * nchunk), dim3(kHwThreads), 0, stream,
