@@ -479,9 +479,10 @@ __device__ __forceinline__ void hw_commit(const HwStage& st, float* dst, int tid
         *reinterpret_cast<f32x4*>(dst + (r0 + (kHwThreads / kHwCh) * i) * kHwStride + 4 * c) = st.v[i];
 }
 
-template <class ARGS>
-__device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][2], float (*red)[kHwTile][kMaxOut], int f0,
-                                            int s0, int bn, int wm, int wn, int n, int hh, int tid);
+// NJ 32-sequence tiles per wave, TS sequences per workgroup; red is [feature wave groups][TS][kMaxOut]
+template <int NJ, int TS, class ARGS>
+__device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][NJ], float (*red)[TS][kMaxOut], int nwm,
+                                            int f0, int s0, int bn, int wm, int wn, int n, int hh, int tid);
 
 __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_dis_highway(const HwArgs a) {
     __shared__ __attribute__((aligned(16))) float As[kHwTile * kHwStride];  // hw_w rows (output features)
@@ -541,7 +542,7 @@ __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2
         }
     }
 
-    hw_epilogue(a, acc, red, f0, s0, bn, wm, wn, n, hh, tid);
+    hw_epilogue<2, kHwTile>(a, acc, red, 2, f0, s0, bn, wm, wn, n, hh, tid);
 }
 
 // ---- highway GEMM on split-fp16 operands (TG_DIS_SPLIT_F16): W_hw pre-split into (hi, lo) halves by k_split, the
@@ -555,30 +556,33 @@ struct HsArgs {
 };
 
 struct HsStage { f16x8 v[4]; };
+template <int NT>
 __device__ __forceinline__ void hs_fetch(HsStage& st, const _Float16* src, int row0, int nrows, int k0, int F, int tid) {
-    const int c = tid & 7, r0 = tid >> 3;  // 8 chunks of 8 halves per row, 32 rows per pass
+    const int c = tid & 7, r0 = tid >> 3;  // 8 chunks of 8 halves per row, NT/8 rows per pass
     const int k = k0 + 8 * c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = tg_min(row0 + r0 + 32 * i, nrows - 1);
+        const int row = tg_min(row0 + r0 + (NT / 8) * i, nrows - 1);
         f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
         if (k < F) v = *reinterpret_cast<const f16x8*>(src + (size_t)row * F + k);
         st.v[i] = v;
     }
 }
+template <int NT>
 __device__ __forceinline__ void hs_commit(const HsStage& st, _Float16* dst, int tid) {
     const int c = tid & 7, r0 = tid >> 3;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(dst + (r0 + 32 * i) * kHsStride + 8 * c) = st.v[i];
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(dst + (r0 + (NT / 8) * i) * kHsStride + 8 * c) = st.v[i];
 }
 // the fp32 operand (pooled): same tile shape, 8 floats per (row, chunk)
 struct HsStageF { f32x4 v[4][2]; };
+template <int NT>
 __device__ __forceinline__ void hs_fetch_f32(HsStageF& st, const float* src, int row0, int nrows, int k0, int F, int tid) {
     const int c = tid & 7, r0 = tid >> 3;
     const int k = k0 + 8 * c;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int row = tg_min(row0 + r0 + 32 * i, nrows - 1);
+        const int row = tg_min(row0 + r0 + (NT / 8) * i, nrows - 1);
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         st.v[i][0] = z;
         st.v[i][1] = z;
@@ -589,6 +593,7 @@ __device__ __forceinline__ void hs_fetch_f32(HsStageF& st, const float* src, int
         }
     }
 }
+template <int NT>
 __device__ __forceinline__ void hs_commit_split(const HsStageF& st, _Float16* hi, _Float16* lo, float sc, int tid) {
     const int c = tid & 7, r0 = tid >> 3;
 #pragma unroll
@@ -600,78 +605,171 @@ __device__ __forceinline__ void hs_commit_split(const HsStageF& st, _Float16* hi
             h[e] = (_Float16)x;
             l[e] = (_Float16)(x - (float)h[e]);
         }
-        *reinterpret_cast<f16x8*>(hi + (r0 + 32 * i) * kHsStride + 8 * c) = h;
-        *reinterpret_cast<f16x8*>(lo + (r0 + 32 * i) * kHsStride + 8 * c) = l;
+        *reinterpret_cast<f16x8*>(hi + (r0 + (NT / 8) * i) * kHsStride + 8 * c) = h;
+        *reinterpret_cast<f16x8*>(lo + (r0 + (NT / 8) * i) * kHsStride + 8 * c) = l;
     }
 }
 
-__global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// Epilogue of the split kernel (F % 8 == 0): the accumulators (h without its bias) go through LDS so that the
+// element-wise part runs row-major -- 32 consecutive threads own one sequence row of the tile, 4 features each:
+// pooled / dropout reads and the feature store are 512-B contiguous per row instead of 16-B pieces of 64 rows per
+// instruction, and with the accumulators dead every thread's loads (all its rows) are in flight before the first use.
+template <int NJ, int TF, int TS, int NT, class ARGS>
+__device__ __forceinline__ void hw_epilogue_rows(const ARGS& a, f32x16 (&acc)[2][NJ], float* ht, int f0, int s0, int bn,
+                                                 int wm, int wn, int n, int hh, int tid) {
+    constexpr int HS = TF + 4;            // h tile row stride (floats)
+    constexpr int RP = NT / (TF / 4);     // rows per pass
+    constexpr int NP = TS / RP;           // passes
+    static_assert(TF / 4 == 32, "one row = 32 threads (the reduction below is over 32 lanes)");
+    const int F = a.w.F, n_out = a.w.n_out;
+#pragma unroll
+    for (int jn = 0; jn < NJ; ++jn)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                float* d = ht + (wn * (32 * NJ) + jn * 32 + n) * HS + wm * 64 + i * 32 + 8 * rq + 4 * hh;
+                *reinterpret_cast<f32x4*>(d) =
+                    f32x4{acc[i][jn][4 * rq], acc[i][jn][4 * rq + 1], acc[i][jn][4 * rq + 2], acc[i][jn][4 * rq + 3]};
+            }
+    __syncthreads();
+    const int c4 = tid & 31, r8 = tid >> 5;
+    const int fb = f0 + 4 * c4;           // this thread's 4 features (all inside or all outside F: F % 4 == 0)
+    const bool fin = fb < F;
+    f32x4 pv[NP], uv[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int seqc = tg_min(s0 + p * RP + r8, a.N - 1);
+        const size_t o4 = (size_t)seqc * F + fb;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        pv[p] = z;
+        uv[p] = z;
+        if (fin) {
+            pv[p] = *reinterpret_cast<const f32x4*>(a.pooled + o4);
+            if (a.dropout_u) uv[p] = *reinterpret_cast<const f32x4*>(a.dropout_u + o4);
+        }
+    }
+    float hb4[4], ow[kMaxOut][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        hb4[e] = fin ? a.w.hw_b[fb + e] : 0.f;
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) ow[o][e] = (fin && o < n_out) ? a.w.out_w[(size_t)o * F + fb + e] : 0.f;
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) {
+        const int row = p * RP + r8;
+        const int seq = s0 + row;
+        const f32x4 hv = *reinterpret_cast<const f32x4*>(ht + row * HS + 4 * c4);
+        float fv[4], part[kMaxOut];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) part[o] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float h = hv[e] + hb4[e];
+            const float sg = tg_sigmoid(h);
+            fv[e] = sg * __builtin_fmaxf(h, 0.f) + (1.f - sg) * pv[p][e];
+        }
+        if (a.feature_out && fin && seq < a.N)
+            *reinterpret_cast<f32x4*>(a.feature_out + (size_t)seq * F + fb) = f32x4{fv[0], fv[1], fv[2], fv[3]};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float d = fin ? fv[e] : 0.f;
+            if (a.dropout_u) d = (uv[p][e] < a.keep) ? d * a.scale : 0.f;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o)
+                if (o < n_out) part[o] = __builtin_fmaf(d, ow[o][e], part[o]);
+        }
+        // fixed tree over the row's 32 threads
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) {
+            if (o < n_out) {
+#pragma unroll
+                for (int off = 1; off < 32; off <<= 1) part[o] += __shfl_xor(part[o], off, 64);
+            }
+        }
+        if (c4 == 0 && seq < a.N) {
+            float* po = a.partial + ((size_t)seq * a.nchunk + bn) * kMaxOut;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o)
+                if (o < n_out) po[o] = part[o];
+        }
+    }
+}
+
+// Workgroup tile = (64*WF features) x (32*NJ*WS sequences), one wave per (feature group, sequence group), 2 x NJ
+// accumulators of 32 x 32 per wave.  Used as <2,2,2>: 128 x 128, 256 threads, two workgroups per CU.
+template <int WF, int WS, int NJ>
+__global__ __launch_bounds__(64 * WF * WS) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_dis_highway_split(const HsArgs a) {
-    // 4 operand tiles of 18 KiB; the epilogue's cross-wave partials reuse the first one, so that two workgroups
-    // (two waves per SIMD) fit a CU's 160 KiB: one's barrier waits run under the other's MFMAs
-    __shared__ __attribute__((aligned(16))) _Float16 tiles[4 * kHwTile * kHsStride];
+    constexpr int TF = 64 * WF, TS = 32 * NJ * WS, NT = 64 * WF * WS;
+    static_assert(TF * 8 == NT * 4 && TS * 8 == NT * 4, "fetch helpers: 4 passes of NT/8 rows cover a tile");
+    // operand tiles (hi, lo of both); the epilogue's cross-wave partials reuse the space
+    extern __shared__ __attribute__((aligned(16))) _Float16 tiles[];
     _Float16* Ah = tiles;
-    _Float16* Al = tiles + kHwTile * kHsStride;
-    _Float16* Bh = tiles + 2 * kHwTile * kHsStride;
-    _Float16* Bl = tiles + 3 * kHwTile * kHsStride;
-    static_assert(sizeof(float) * 2 * kHwTile * kMaxOut <= sizeof(_Float16) * kHwTile * kHsStride, "red must fit a tile");
-    float (*red)[kHwTile][kMaxOut] = reinterpret_cast<float (*)[kHwTile][kMaxOut]>(tiles);
+    _Float16* Al = Ah + TF * kHsStride;
+    _Float16* Bh = Al + TF * kHsStride;
+    _Float16* Bl = Bh + TS * kHsStride;
+    static_assert(sizeof(float) * TS * (TF + 4) <= sizeof(_Float16) * 2 * (TF + TS) * kHsStride, "h tile must fit");
 
     const int F = a.h.w.F;
     const int tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv >> 1, wn = wv & 1;
+    const int wm = wv / WS, wn = wv % WS;
     const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
     // Workgroups go to the 8 XCDs round-robin by blockIdx.  XCD x takes the sequence tiles bm = x (mod 8) and walks
-    // all feature chunks of one tile before the next, so the workgroups resident on an XCD together share their
-    // pooled tile 14 ways and the W_hw slabs ~4 ways inside that XCD's L2 (the operands, 371 MB, do not fit it).
+    // all feature chunks of one tile before the next, so the workgroups resident on an XCD together share operands
+    // inside that XCD's L2 as far as their phases allow.
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int bn = jx % a.h.nchunk, bm = (jx / a.h.nchunk) * 8 + xcd;
     if (bm >= a.h.nseqtile) return;
-    const int f0 = bn * kHwTile, s0 = bm * kHwTile;
+    const int f0 = bn * TF, s0 = bm * TS;
     const size_t wlo = (size_t)F * F;
     const float sp = a.scales[1];
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NJ];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     HsStage sah, sal;
     HsStageF sb;
-    hs_fetch(sah, a.w_hi, f0, F, 0, F, tid);
-    hs_fetch(sal, a.w_hi + wlo, f0, F, 0, F, tid);
-    hs_fetch_f32(sb, a.h.pooled, s0, a.h.N, 0, F, tid);
+    hs_fetch<NT>(sah, a.w_hi, f0, F, 0, F, tid);
+    hs_fetch<NT>(sal, a.w_hi + wlo, f0, F, 0, F, tid);
+    hs_fetch_f32<NT>(sb, a.h.pooled, s0, a.h.N, 0, F, tid);
     for (int k0 = 0; k0 < F; k0 += kHsBK) {
         __syncthreads();
-        hs_commit(sah, Ah, tid);
-        hs_commit(sal, Al, tid);
-        hs_commit_split(sb, Bh, Bl, sp, tid);
+        hs_commit<NT>(sah, Ah, tid);
+        hs_commit<NT>(sal, Al, tid);
+        hs_commit_split<NT>(sb, Bh, Bl, sp, tid);
         __syncthreads();
         if (k0 + kHsBK < F) {
-            hs_fetch(sah, a.w_hi, f0, F, k0 + kHsBK, F, tid);
-            hs_fetch(sal, a.w_hi + wlo, f0, F, k0 + kHsBK, F, tid);
-            hs_fetch_f32(sb, a.h.pooled, s0, a.h.N, k0 + kHsBK, F, tid);
+            hs_fetch<NT>(sah, a.w_hi, f0, F, k0 + kHsBK, F, tid);
+            hs_fetch<NT>(sal, a.w_hi + wlo, f0, F, k0 + kHsBK, F, tid);
+            hs_fetch_f32<NT>(sb, a.h.pooled, s0, a.h.N, k0 + kHsBK, F, tid);
         }
 #pragma unroll
         for (int ks = 0; ks < kHsBK / 16; ++ks) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            f16x8 ah[2], al[2], bh[NJ], bl[NJ];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int ao = (wm * 64 + i * 32 + n) * kHsStride + 16 * ks + 8 * hh;
-                const int bo = (wn * 64 + i * 32 + n) * kHsStride + 16 * ks + 8 * hh;
                 ah[i] = *reinterpret_cast<const f16x8*>(Ah + ao);
                 al[i] = *reinterpret_cast<const f16x8*>(Al + ao);
-                bh[i] = *reinterpret_cast<const f16x8*>(Bh + bo);
-                bl[i] = *reinterpret_cast<const f16x8*>(Bl + bo);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int bo = (wn * (32 * NJ) + j * 32 + n) * kHsStride + 16 * ks + 8 * hh;
+                bh[j] = *reinterpret_cast<const f16x8*>(Bh + bo);
+                bl[j] = *reinterpret_cast<const f16x8*>(Bl + bo);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
+                for (int jn = 0; jn < NJ; ++jn) {
                     acc[i][jn] = TG_MFMA16(ah[i], bh[jn], acc[i][jn]);
                     acc[i][jn] = TG_MFMA16(ah[i], bl[jn], acc[i][jn]);
                     acc[i][jn] = TG_MFMA16(al[i], bh[jn], acc[i][jn]);
@@ -682,27 +780,27 @@ void k_dis_highway_split(const HsArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NJ; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
-    __syncthreads();  // the last tile's reads are done before red overwrites it
-    hw_epilogue(a.h, acc, red, f0, s0, bn, wm, wn, n, hh, tid);
+    __syncthreads();  // the last tile's reads are done before the epilogue reuses the space
+    hw_epilogue_rows<NJ, TF, TS, NT>(a.h, acc, reinterpret_cast<float*>(tiles), f0, s0, bn, wm, wn, n, hh, tid);
 }
 
-template <class ARGS>
-__device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][2], float (*red)[kHwTile][kMaxOut], int f0,
-                                            int s0, int bn, int wm, int wn, int n, int hh, int tid) {
+template <int NJ, int TS, class ARGS>
+__device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][NJ], float (*red)[TS][kMaxOut], int nwm,
+                                            int f0, int s0, int bn, int wm, int wn, int n, int hh, int tid) {
     const int F = a.w.F, n_out = a.w.n_out;
     // ---- epilogue: gate, dropout, partial feature2out dot (lane = sequence, regs = features)
-    float part[2][kMaxOut];
+    float part[NJ][kMaxOut];
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
+    for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) part[jn][o] = 0.f;
     const bool vec = (F & 3) == 0;
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn) {
-        const int seq = s0 + wn * 64 + jn * 32 + n;
+    for (int jn = 0; jn < NJ; ++jn) {
+        const int seq = s0 + wn * (32 * NJ) + jn * 32 + n;
         const int seqc = tg_min(seq, a.N - 1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -753,24 +851,28 @@ __device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][2], 
             }
         }
     }
-    // lanes n and n+32 hold the same sequence; then the two feature-half waves (wm = 0,1)
+    // lanes n and n+32 hold the same sequence; then the feature wave groups (wm = 0..nwm-1, fixed order)
 #pragma unroll
-    for (int jn = 0; jn < 2; ++jn)
+    for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
         for (int o = 0; o < kMaxOut; ++o) part[jn][o] += __shfl_xor(part[jn][o], 32, 64);
     if (hh == 0) {
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < NJ; ++jn)
 #pragma unroll
-            for (int o = 0; o < kMaxOut; ++o) red[wm][wn * 64 + jn * 32 + n][o] = part[jn][o];
+            for (int o = 0; o < kMaxOut; ++o) red[wm][wn * (32 * NJ) + jn * 32 + n][o] = part[jn][o];
     }
     __syncthreads();
-    if (tid < kHwTile) {
+    if (tid < TS) {
         const int seq = s0 + tid;
         if (seq < a.N) {
             float* po = a.partial + ((size_t)seq * a.nchunk + bn) * kMaxOut;
 #pragma unroll
-            for (int o = 0; o < kMaxOut; ++o) po[o] = red[0][tid][o] + red[1][tid][o];
+            for (int o = 0; o < kMaxOut; ++o) {
+                float v = red[0][tid][o];
+                for (int g = 1; g < nwm; ++g) v += red[g][tid][o];
+                po[o] = v;
+            }
         }
     }
 }
@@ -969,6 +1071,29 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     return TG_OK;
 }
 
+template <int WF, int WS, int NJ>
+int launch_highway_split(HsArgs& hs, hipStream_t stream) {
+    constexpr int TF = 64 * WF, TS = 32 * NJ * WS;
+    constexpr size_t sm = sizeof(_Float16) * 2 * (TF + TS) * kHsStride;
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_highway_split<WF, WS, NJ>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
+        if (e != hipSuccess) {
+            tg_set_error("hipFuncSetAttribute(k_dis_highway_split): %s", hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        attr_set = true;
+    }
+    hs.h.nchunk = (hs.h.w.F + TF - 1) / TF;
+    hs.h.nseqtile = (hs.h.N + TS - 1) / TS;
+    tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
+    hipLaunchKernelGGL((k_dis_highway_split<WF, WS, NJ>), dim3(8 * ((hs.h.nseqtile + 7) / 8) * hs.h.nchunk),
+                       dim3(64 * WF * WS), sm, stream, hs);
+    tg_prof_end(stream);
+    return TG_OK;
+}
+
 // sentences == nullptr: plain scoring of N arbitrary sequences.
 // sentences != nullptr: seqs is [R,L,B,L] rollout completions (N = R*L*B), prefix reuse.
 int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const int64_t* sentences, int B, int col,
@@ -1051,6 +1176,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     ha.scale = 1.f / (1.f - dropout_p);
     ha.N = N;
     ha.nchunk = nchunk;
+    int nchunk_used = nchunk;
     ha.nseqtile = (N + kHwTile - 1) / kHwTile;
     if (w->precision == TG_DIS_SPLIT_F16 && (w->F & 7) == 0) {
         // scales from |max| of hw_w and of the pooled features (the conv kernels' epilogue left that one), then the
@@ -1069,10 +1195,11 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         hs.h = ha;
         hs.w_hi = hw16;
         hs.scales = scales;
-        tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
-        hipLaunchKernelGGL(k_dis_highway_split, dim3(8 * ((ha.nseqtile + 7) / 8) * nchunk), dim3(kHwThreads), 0, stream,
-                           hs);
-        tg_prof_end(stream);
+        // 128 x 128 tiles, two workgroups per CU.  (256 x 256 with 512 threads -- <4,2,4> -- halves the operand traffic
+        // but measured 1.7x slower on MI355X: one workgroup per CU, 86 spilled registers, barrier stalls uncovered.)
+        rc = launch_highway_split<2, 2, 2>(hs, stream);
+        if (rc) return rc;
+        nchunk_used = hs.h.nchunk;
     } else {
         tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
         hipLaunchKernelGGL(k_dis_highway, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, ha);
@@ -1086,7 +1213,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     fa.reward_out = reward_out;
     fa.logits_out = logits_out;
     fa.N = N;
-    fa.nchunk = nchunk;
+    fa.nchunk = nchunk_used;
     fa.n_out = w->n_out;
     fa.col = col;
     tg_prof_begin(TG_KERNEL_DIS_FINAL, stream);
