@@ -96,12 +96,56 @@ def cpu_baseline(wl, budget_s=15.0):
             "sample": "same workload at rollout_num %d (%d completions, %.1f s)" % (R, R * L * B, t)}
 
 
+def bench_nll(args, dev):
+    """Side workload c5 (BASELINE configs[4]): NLL.cal_nll over 99 968 sequences (100 000 with drop_last at batch 64),
+    V5000 L20 E=H=32 -- one teacher-forced launch, fp32 throughout.  Not the headline metric: prints sequences/s."""
+    V, L, E, H, N, batch = 5000, 20, 32, 32, 99968, 64
+    gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=1.0, device=dev)
+    samples = torch.from_numpy(tg.synth.tokens(5, (N, L), V)).to(dev)
+    for _ in range(args.warmup):
+        tg.nll.nll_of_samples(gen, samples, batch)
+    torch.cuda.synchronize()
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        nll, _pb = tg.nll.nll_of_samples(gen, samples, batch)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ms, n = tg._lib.profile_read()["gen_teacher"]
+    tg._lib.profile_enable(False)
+    flops = (2 * H * V + 8 * H * (E + H)) * N * L
+    ach = flops / (ms / n * 1e-3) / 1e12
+    out = {"metric": "NLL sequences/sec", "value": N * args.steps / dt, "unit": "sequences/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "configs[4] NLL_gen over 99968 sequences: vocab 5000, len 20, emb/hidden 32, batch 64",
+                      "tokens_per_step": N * L, "nll": nll},
+           "roofline": {"kernel": "gen_teacher", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "flops_per_launch": flops, "avg_launch_ms": ms / n}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        og = oracle.Gen(tg.synth.gen_state(V, E, H, seed=0, std=1.0))
+        ns = 8192
+        s = samples[:ns].cpu().numpy()
+        inp = np.concatenate([np.ones((ns, 1), np.int64), s[:, :-1]], 1)
+        t0 = time.perf_counter()
+        oracle.gen_teacher_forced(og, inp, s)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": ns / t, "unit": "sequences/s", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": "first %d sequences (%.1f s)" % (ns, t)}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
     ap.add_argument("--dis-precision", default=None, choices=["fp32", "split_f16"],
@@ -122,6 +166,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
+    if args.workload == "c5":
+        if world > 1:
+            raise SystemExit("workload c5 (NLL) is a single-GPU side measurement")
+        return bench_nll(args, dev)
     wl = WORKLOADS[args.workload]
     V, L, E, H, B = wl["V"], wl["L"], wl["E"], wl["H"], wl["B"]
     R = wl["R"] * world  # weak scaling: rollout_num 16 per GPU
