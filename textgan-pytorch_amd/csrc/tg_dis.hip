@@ -130,7 +130,10 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         const int K = f * kEd, T = L - f + 1;
         const int arow = tg_min(mt * 32 + n, nk - 1);
         const float* wp = a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
-        const int ntile = (T + TT - 1) >> (5 - log2S);  // ceil(T / TT)
+        // windows t <= g - f lie inside the shared prefix (Prefix mode): tiles start at the first fresh window of the
+        // workgroup's smallest given_num, not at a multiple of the tile's time span
+        const int t_org = (MODE == kConvPrefix) ? tg_max(0, g_min - f + 1) : 0;
+        const int ntile = tg_max(0, T - t_org + TT - 1) >> (5 - log2S);  // ceil((T - t_org) / TT), 0 if none is fresh
 
         float runmax[16];
 #pragma unroll
@@ -143,14 +146,14 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
             for (int nt = 0; nt < 4; ++nt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[nt][r] = 0.f;
-                const int t = tg_min((nb0 + nt) * TT + tsub, T - 1);
+                const int t = tg_min(t_org + (nb0 + nt) * TT + tsub, T - 1);
                 boff[nt] = SPLIT ? (t * S + s) * kERowH + 8 * hh : (t * S + s) * kERow + 32 * hh;
             }
         };
         auto finish_chunk = [&](int nb0, int nbc) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
-                const int tw = (nb0 + nt) * TT + tsub;
+                const int tw = t_org + (nb0 + nt) * TT + tsub;
                 const bool ok = (nt < nbc) && (tw < T);
                 if (MODE == kConvStoreAll) {
                     if (ok && seq0 + s < a.N) {
@@ -171,8 +174,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
             }
         };
 
-        // windows t <= g - f lie inside the shared prefix: start at the first tile with a fresh window
-        const int nb_start = (MODE == kConvPrefix) ? (tg_max(0, g_min - f + 1) >> (5 - log2S)) : 0;
+        const int nb_start = 0;
         if constexpr (SPLIT) {
             // A fragments of (k, mt) in load order (k_split_weights): [tau][8 pieces][64 lanes] x 16 B, pieces 0-3 the
             // hi halves of k blocks 0-3, pieces 4-7 their lo halves.  One flat loop over (chunk of 4 N-tiles, tau)
