@@ -35,6 +35,21 @@ constexpr int kConvStoreAll = 1;// base sentences: every window's conv+bias valu
 constexpr int kConvPrefix = 2;  // rollout completions [R,L,B,L]: sequence n = (i, g-1, b) shares its first g tokens
                                 // with sentence b, so windows inside the prefix come from the running-max table
 
+constexpr int kMaxMerged = 4;
+// A mixed-width tile (split path): the banks' remainder rows (n_k mod 32) packed 32 to a tile.  Row i carries filter
+// j[i] of bank k[i]; the tile runs fmax window rows with zero weights past each row's own width, over the positions
+// of its narrowest member.  Per-row epilogue data lives in device memory (k_split_weights writes it).
+struct MergedMeta {
+    float bias[32];
+    int feat[32];  // global feature index, -1 = unused row
+    int fw[32];    // the row's filter width
+};
+struct MergedTile {
+    uint8_t nrow, fmax, fmin, pad;
+    uint8_t k[32];
+    uint8_t j[32];  // filter index inside its bank (remainder rows start at (n_k/32)*32 <= 224)
+};
+
 struct ConvArgs {
     TgDisWeights w;
     const int64_t* seqs;  // [N,L]
@@ -51,6 +66,11 @@ struct ConvArgs {
     const float* scales;
     unsigned* pooled_absmax;   // nullable: max of the pooled features as ordered bits (they are >= 0), for the highway's scale
     int woff[TG_MAX_FILTERS];
+    int n_merged;              // mixed-width remainder tiles (items with k == 0xFF, mt = tile index); split path only
+    int pad_rows;              // zero rows kept after the sequence in LDS: max (fmax - fmin) over the merged tiles
+    int mwoff[kMaxMerged];     // halves offset of a merged tile's fragments in w16
+    uint8_t mfmax[kMaxMerged], mfmin[kMaxMerged];
+    const MergedMeta* mmeta;   // [n_merged]
     ConvItem items[kMaxItems]; // sorted by cost, heaviest first
 };
 
@@ -70,7 +90,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     float* ebuf = reinterpret_cast<float*>(smem);  // [L][S][68] floats, or [L][S][136] halves (same bytes)
     _Float16* ebuf_h = reinterpret_cast<_Float16*>(smem);
     const int L = a.L, S = a.S, log2S = a.log2S, TT = 32 >> log2S;
-    int* ctr = reinterpret_cast<int*>(ebuf + (size_t)L * S * kERow);
+    int* ctr = reinterpret_cast<int*>(ebuf + (size_t)(L + a.pad_rows) * S * kERow);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -102,6 +122,9 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
             *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + kEd + 4 * c) = l;
         }
     }
+    // zero rows behind the sequence: a merged tile's wider members read past position L - 1 against zero weights
+    for (int idx = tid; idx < a.pad_rows * S * (kERow / 4); idx += kConvThreads)
+        *reinterpret_cast<f32x4*>(ebuf + (size_t)L * S * kERow + 4 * idx) = f32x4{0.f, 0.f, 0.f, 0.f};
     if (tid == 0) *ctr = 0;
     __syncthreads();
 
@@ -126,10 +149,14 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         item = __builtin_amdgcn_readfirstlane(item);
         if (item >= a.n_items) break;
         const int k = a.items[item].k, mt = a.items[item].mt;
-        const int f = a.w.f[k], nk = a.w.n[k];
-        const int K = f * kEd, T = L - f + 1;
+        const bool merged = SPLIT && k == 0xFF;  // mt = merged tile index
+        const int f = merged ? a.mfmax[mt] : a.w.f[k];
+        const int nk = merged ? 32 : a.w.n[k];
+        const int K = f * kEd, T = L - (merged ? a.mfmin[mt] : f) + 1;
         const int arow = tg_min(mt * 32 + n, nk - 1);
-        const float* wp = a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
+        const float* wp = merged ? nullptr : a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
+        const MergedMeta* mm = merged ? a.mmeta + mt : nullptr;
+        auto mrow = [&](int r) { return (r & 3) + 8 * (r >> 2) + 4 * hh; };  // tile row of accumulator register r
         // windows t <= g - f lie inside the shared prefix (Prefix mode): tiles start at the first fresh window of the
         // workgroup's smallest given_num, not at a multiple of the tile's time span
         const int t_org = (MODE == kConvPrefix) ? tg_max(0, g_min - f + 1) : 0;
@@ -155,7 +182,22 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
             for (int nt = 0; nt < 4; ++nt) {
                 const int tw = t_org + (nb0 + nt) * TT + tsub;
                 const bool ok = (nt < nbc) && (tw < T);
-                if (MODE == kConvStoreAll) {
+                if (merged) {  // per-row width: position tw exists for row r iff tw + fw <= L
+                    if (MODE == kConvStoreAll) {
+                        if (ok && seq0 + s < a.N) {
+                            float* po = a.cv + ((size_t)(seq0 + s) * L + tw) * a.w.F;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int ft = mm->feat[mrow(r)];
+                                if (ft >= 0 && tw + mm->fw[mrow(r)] <= L) po[ft] = acc[nt][r] + mm->bias[mrow(r)];
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            runmax[r] = __builtin_fmaxf(runmax[r], (ok && tw + mm->fw[mrow(r)] <= L) ? acc[nt][r] : TG_NEG_INF);
+                    }
+                } else if (MODE == kConvStoreAll) {
                     if (ok && seq0 + s < a.N) {
                         float* po = a.cv + ((size_t)(seq0 + s) * L + tw) * a.w.F + a.foff[k];
                         const float* pb = a.w.conv_b[k];
@@ -179,7 +221,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
             // A fragments of (k, mt) in load order (k_split_weights): [tau][8 pieces][64 lanes] x 16 B, pieces 0-3 the
             // hi halves of k blocks 0-3, pieces 4-7 their lo halves.  One flat loop over (chunk of 4 N-tiles, tau)
             // with the next stage's fragment in flight in a second register set.
-            const f16x8* wfrag = reinterpret_cast<const f16x8*>(a.w16 + a.woff[k]) + ((size_t)mt * f * 8) * 64 + lane;
+            const f16x8* wfrag = merged ? reinterpret_cast<const f16x8*>(a.w16 + a.mwoff[mt]) + lane
+                                        : reinterpret_cast<const f16x8*>(a.w16 + a.woff[k]) + ((size_t)mt * f * 8) * 64 + lane;
             const float inv = a.scales[2];
             const int total = ((ntile - nb_start + 3) >> 2) * f;
             int tau = 0, nb0 = nb_start;
@@ -271,6 +314,22 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], __shfl_xor(runmax[r], off, 64));
         }
+        if (merged) {
+            if (tsub == 0 && seq0 + s < a.N) {
+                float* po = a.pooled + (size_t)(seq0 + s) * a.w.F;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ft = mm->feat[mrow(r)], fwr = mm->fw[mrow(r)];
+                    if (ft < 0) continue;
+                    float o = __builtin_fmaxf(runmax[r] + mm->bias[mrow(r)], 0.f);
+                    if (MODE == kConvPrefix && g_lane >= fwr)
+                        o = __builtin_fmaxf(o, a.cv[((size_t)b_lane * L + (g_lane - fwr)) * a.w.F + ft]);
+                    po[ft] = o;
+                    pmax = __builtin_fmaxf(pmax, o);
+                }
+            }
+            continue;
+        }
         // bias + ReLU, store: D reg r -> filter mt*32 + (r&3) + 8*(r>>2) + 4*hh
         if (tsub == 0 && seq0 + s < a.N) {
             float* po = a.pooled + (size_t)(seq0 + s) * a.w.F + a.foff[k];
@@ -347,12 +406,19 @@ __global__ void k_make_scales(const unsigned* absmax, float* scales) {
 
 struct SplitArgs {
     const float* src[TG_MAX_FILTERS];
+    const float* bias[TG_MAX_FILTERS];
     int woff[TG_MAX_FILTERS];   // halves
-    int nk[TG_MAX_FILTERS];
+    int nk[TG_MAX_FILTERS];     // filters of the bank
+    int nfull[TG_MAX_FILTERS];  // rows written as the bank's own tiles (a multiple of 32 if its remainder was merged)
     int f[TG_MAX_FILTERS];
+    int foff[TG_MAX_FILTERS];
     int n_filters;
     _Float16* w16;
     const float* scales;
+    int n_merged;
+    int mwoff[kMaxMerged];
+    MergedTile merged[kMaxMerged];
+    MergedMeta* mmeta;
 };
 
 // Conv weights -> scaled (hi, lo) fp16 halves in the order k_dis_conv<.., SPLIT> loads them: bank k, 32-filter tile
@@ -360,10 +426,49 @@ struct SplitArgs {
 // W[min(mt*32 + (lane&31), n_k-1)][tau*64 + 16*(p&3) + 8*(lane>>5) + 0..7] -- one 16-B store per thread, and every
 // load instruction of a wave reads 1 KiB contiguous.
 __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
-    const int k = blockIdx.y;
     const float sc = a.scales[0];
+    if ((int)blockIdx.y >= a.n_filters) {  // a merged tile: [tau < fmax][8 pieces][64 lanes], zero past a row's width
+        const int m = blockIdx.y - a.n_filters;
+        const MergedTile& mt = a.merged[m];
+        const int total = mt.fmax * 8 * 64;
+        f16x8* dst = reinterpret_cast<f16x8*>(a.w16 + a.mwoff[m]);
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+            const int lane = i & 63, p = (i >> 6) & 7, tau = i >> 9;
+            const int row = lane & 31;
+            f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (row < mt.nrow) {
+                const int k = mt.k[row], fk = a.f[k];
+                if (tau < fk) {
+                    const float* src = a.src[k] + (size_t)mt.j[row] * fk * kEd + tau * kEd + 16 * (p & 3) + 8 * (lane >> 5);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float x = src[e] * sc;
+                        const _Float16 h = (_Float16)x;
+                        o[e] = (p < 4) ? h : (_Float16)(x - (float)h);
+                    }
+                }
+            }
+            dst[i] = o;
+        }
+        if (blockIdx.x == 0 && threadIdx.x < 32) {
+            const int row = threadIdx.x;
+            MergedMeta& mm = a.mmeta[m];
+            if (row < mt.nrow) {
+                const int k = mt.k[row];
+                mm.bias[row] = a.bias[k][mt.j[row]];
+                mm.feat[row] = a.foff[k] + mt.j[row];
+                mm.fw[row] = a.f[k];
+            } else {
+                mm.bias[row] = 0.f;
+                mm.feat[row] = -1;
+                mm.fw[row] = mt.fmin;
+            }
+        }
+        return;
+    }
+    const int k = blockIdx.y;
     const int f = a.f[k], nk = a.nk[k], K = f * kEd;
-    const int total = ((nk + 31) / 32) * f * 8 * 64;
+    const int total = ((a.nfull[k] + 31) / 32) * f * 8 * 64;
     f16x8* dst = reinterpret_cast<f16x8*>(a.w16 + a.woff[k]);
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int lane = i & 63, p = (i >> 6) & 7, mtau = i >> 9;
@@ -952,25 +1057,72 @@ inline int tg_min_host(int a, int b) { return a < b ? a : b; }
 
 namespace {
 
+// Mixed-width tiles from the banks' remainder rows (split path): remainders sorted by width, packed greedily 32
+// rows to a tile; a tile with a single member is left to the bank's own partial tile.
+struct MergePlan {
+    int n_merged;
+    MergedTile tile[kMaxMerged];
+    bool bank_merged[TG_MAX_FILTERS];  // the bank's remainder rows live in a merged tile
+    int pad_rows;
+};
+
+MergePlan plan_merge(const TgDisWeights* w) {
+    MergePlan pl = {};
+    if (w->precision != TG_DIS_SPLIT_F16) return pl;
+    int order[TG_MAX_FILTERS], no = 0;
+    for (int k = 0; k < w->n_filters; ++k)
+        if (w->n[k] % 32 != 0 && w->n[k] < 256 && w->f[k] < 256) order[no++] = k;
+    for (int i = 1; i < no; ++i) {  // by width
+        const int t = order[i];
+        int j = i - 1;
+        while (j >= 0 && w->f[order[j]] > w->f[t]) { order[j + 1] = order[j]; --j; }
+        order[j + 1] = t;
+    }
+    int i = 0;
+    while (i < no && pl.n_merged < kMaxMerged) {
+        int rows = 0, j = i;
+        while (j < no && rows + w->n[order[j]] % 32 <= 32) { rows += w->n[order[j]] % 32; ++j; }
+        if (j - i >= 2) {
+            MergedTile& t = pl.tile[pl.n_merged++];
+            t.nrow = 0;
+            t.fmin = (uint8_t)w->f[order[i]];
+            t.fmax = (uint8_t)w->f[order[j - 1]];
+            for (int q = i; q < j; ++q) {
+                const int k = order[q], base = (w->n[k] / 32) * 32;
+                for (int r = base; r < w->n[k]; ++r) { t.k[t.nrow] = (uint8_t)k; t.j[t.nrow] = (uint8_t)r; ++t.nrow; }
+                pl.bank_merged[k] = true;
+            }
+            if (t.fmax - t.fmin > pl.pad_rows) pl.pad_rows = t.fmax - t.fmin;
+        }
+        i = (j > i) ? j : i + 1;
+    }
+    return pl;
+}
+
 int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem) {
     ca.w = *w;
     ca.L = L;
+    const MergePlan pl = plan_merge(w);
+    const int LP = L + pl.pad_rows;  // LDS rows per sequence
     int S = 32, log2S = 5;
-    while (S > 1 && (size_t)L * S * kERow * sizeof(float) + 64 > 144 * 1024) { S >>= 1; --log2S; }
+    while (S > 1 && (size_t)LP * S * kERow * sizeof(float) + 64 > 144 * 1024) { S >>= 1; --log2S; }
     // few sequences (the base sentences of the prefix pass): fewer per workgroup so that the grid fills the chip
     while (S > 1 && (N + S - 1) / S < 512) { S >>= 1; --log2S; }
-    if ((size_t)L * S * kERow * sizeof(float) + 64 > 160 * 1024) {
+    if ((size_t)LP * S * kERow * sizeof(float) + 64 > 160 * 1024) {
         tg_set_error("tg_dis_score: sequence length %d too long for the LDS-resident conv kernel", L);
         return TG_ERR_ARG;
     }
     ca.S = S;
     ca.log2S = log2S;
+    ca.pad_rows = pl.pad_rows;
+    ca.n_merged = pl.n_merged;
     int off = 0, ni = 0;
     struct Tmp { int k, mt; long cost; } tmp[kMaxItems];
     for (int k = 0; k < w->n_filters; ++k) {
         ca.foff[k] = off;
         off += w->n[k];
-        for (int mt = 0; mt < (w->n[k] + 31) / 32; ++mt) {
+        const int ntile = pl.bank_merged[k] ? w->n[k] / 32 : (w->n[k] + 31) / 32;
+        for (int mt = 0; mt < ntile; ++mt) {
             if (ni >= kMaxItems) {
                 tg_set_error("tg_dis_score: too many filter tiles (> %d)", kMaxItems);
                 return TG_ERR_ARG;
@@ -978,6 +1130,16 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
             tmp[ni].k = k; tmp[ni].mt = mt; tmp[ni].cost = (long)w->f[k] * (L - w->f[k] + 1);
             ++ni;
         }
+    }
+    for (int m = 0; m < pl.n_merged; ++m) {
+        if (ni >= kMaxItems) {
+            tg_set_error("tg_dis_score: too many filter tiles (> %d)", kMaxItems);
+            return TG_ERR_ARG;
+        }
+        ca.mfmax[m] = pl.tile[m].fmax;
+        ca.mfmin[m] = pl.tile[m].fmin;
+        tmp[ni].k = 0xFF; tmp[ni].mt = m; tmp[ni].cost = (long)pl.tile[m].fmax * (L - pl.tile[m].fmin + 1);
+        ++ni;
     }
     for (int i = 1; i < ni; ++i) {  // insertion sort, heaviest first
         Tmp t = tmp[i];
@@ -987,7 +1149,7 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
     }
     for (int i = 0; i < ni; ++i) { ca.items[i].k = (uint8_t)tmp[i].k; ca.items[i].mt = (uint8_t)tmp[i].mt; }
     ca.n_items = ni;
-    *smem = (size_t)L * S * kERow * sizeof(float) + 64;
+    *smem = (size_t)LP * S * kERow * sizeof(float) + 64;
     return TG_OK;
 }
 
@@ -1014,13 +1176,19 @@ int launch_conv(const ConvArgs& ca, size_t sm, hipStream_t stream) {
     return ca.w16 ? launch_conv_t<MODE, true>(ca, sm, stream) : launch_conv_t<MODE, false>(ca, sm, stream);
 }
 
-// fp16 halves of one bank in fragment order (hi and lo, filter count padded to a multiple of 32)
+// fp16 halves of one bank in fragment order (hi and lo, filter count padded to a multiple of 32); an upper bound
+// when the bank's remainder rows live in a merged tile
 size_t conv_frag_halves(const TgDisWeights* w, int k) { return (size_t)((w->n[k] + 31) / 32) * w->f[k] * 8 * 64 * 8; }
+size_t merged_frag_halves(int fmax) { return (size_t)fmax * 8 * 64 * 8; }
 
-size_t conv_weight_count(const TgDisWeights* w) {  // (hi, lo) pairs
+size_t conv_weight_count(const TgDisWeights* w) {  // (hi, lo) pairs, merged tiles and their row tables included
     size_t n = 0;
-    for (int k = 0; k < w->n_filters; ++k) n += conv_frag_halves(w, k) / 2;
-    return n;
+    int fmax = 1;
+    for (int k = 0; k < w->n_filters; ++k) {
+        n += conv_frag_halves(w, k) / 2;
+        fmax = w->f[k] > fmax ? w->f[k] : fmax;
+    }
+    return n + kMaxMerged * (merged_frag_halves(fmax) / 2 + sizeof(MergedMeta) / 4 + 64);
 }
 
 size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
@@ -1042,13 +1210,18 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     }
     tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
     SplitArgs sa = {};
-    int off = 0, maxcount = 0, maxelems = 0;
+    const MergePlan pl = plan_merge(w);
+    int off = 0, maxcount = 0, maxelems = 0, foff = 0;
     for (int k = 0; k < w->n_filters; ++k) {
         const int cnt = w->n[k] * w->f[k] * kEd;
         sa.src[k] = w->conv_w[k];
+        sa.bias[k] = w->conv_b[k];
         sa.woff[k] = off;
         sa.nk[k] = w->n[k];
+        sa.nfull[k] = pl.bank_merged[k] ? (w->n[k] / 32) * 32 : w->n[k];
         sa.f[k] = w->f[k];
+        sa.foff[k] = foff;
+        foff += w->n[k];
         ca.woff[k] = off;
         const int pieces = (int)(conv_frag_halves(w, k) / 8);
         off += pieces * 8;
@@ -1056,6 +1229,16 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
         maxelems = cnt > maxelems ? cnt : maxelems;
     }
     sa.n_filters = w->n_filters;
+    sa.n_merged = pl.n_merged;
+    for (int m = 0; m < pl.n_merged; ++m) {
+        sa.merged[m] = pl.tile[m];
+        sa.mwoff[m] = off;
+        ca.mwoff[m] = off;
+        off += (int)merged_frag_halves(pl.tile[m].fmax);
+    }
+    off = (off + 127) & ~127;  // the row tables behind the fragments, 256-B aligned
+    sa.mmeta = reinterpret_cast<MergedMeta*>(w16 + off);
+    ca.mmeta = sa.mmeta;
     hipLaunchKernelGGL(k_absmax_banks, dim3(tg_min_host((maxelems + 255) / 256, 64), w->n_filters), dim3(256), 0, stream,
                        sa, absmax);
     const size_t ne = (size_t)w->V * kEd;
@@ -1064,8 +1247,8 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
     sa.w16 = w16;
     sa.scales = scales;
-    hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters), dim3(256), 0,
-                       stream, sa);
+    hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters + pl.n_merged),
+                       dim3(256), 0, stream, sa);
     tg_prof_end(stream);
     ca.w16 = w16;
     ca.scales = scales;
