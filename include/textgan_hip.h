@@ -199,6 +199,24 @@ int tg_dis_score_rollout(const TgDisWeights* w, const int64_t* sentences,
                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Dropout-only re-scoring (MaliGAN reward).
+ * Replaces the loop of MaliGANInstructor.get_mali_reward
+ * (instructor/real_data/maligan_instructor.py:142-147 and the oracle_data
+ * twin): rollout_num forward passes of D over the SAME samples differ only in
+ * their dropout masks, so the features (tg_dis_score's feature_out, the highway
+ * output before dropout) are computed once and this entry point applies R masks
+ * and the output layer:
+ *   reward_out[r, n] = softmax(dropout_r(feature[n, :]) . out_w^T + out_b)[col]
+ *   feature           [N,F]    fp32
+ *   dropout_uniforms  [R,N,F]  fp32: keep iff u < 1-p, kept values scaled 1/(1-p)
+ *   reward_out        [R,N]    fp32
+ * dropout_p = 0 gives R identical rows (eval mode). */
+int tg_dis_rescore_dropout(const TgDisWeights* w, const float* feature, int N,
+                           int R, int col, float dropout_p,
+                           const float* dropout_uniforms, float* reward_out,
+                           void* stream);
+
+/* ---------------------------------------------------------------------------
  * Reward reshape + mean.
  * Replaces torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153):
  * a reinterpretation of the flat [R*L, B] buffer, not a permute:

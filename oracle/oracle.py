@@ -198,3 +198,22 @@ def get_reward(gen, dis, sentences, R, uniforms, col=1, dropout_p=0.0, dropout_u
     if rc:
         raise RuntimeError("oracle: sequence length %d shorter than a filter width" % L)
     return {"completions": comp, "raw": raw, "reward": out}
+
+
+def mali_reward(dis, samples, R, dropout_p=0.0, dropout_uniforms=None):
+    """MaliGANInstructor.get_mali_reward (instructor/real_data/maligan_instructor.py:142-154): R forward passes of D
+    over the same samples (dropout mask r from dropout_uniforms[r]), mean, p/(1-p), normalise, centre, expand."""
+    samples = _i64(samples)
+    B, L = samples.shape
+    rows = []
+    for r in range(R):
+        du = None if dropout_uniforms is None else dropout_uniforms[r]
+        rows.append(dis_forward(dis, samples, col=1, dropout_p=dropout_p, dropout_uniforms=du)["reward"])
+    s = np.zeros(B, np.float32)
+    for row in rows:                       # torch.mean over the stacked dim: sequential fp32 sum / R
+        s = (s + row).astype(np.float32)
+    rew = (s / np.float32(R)).astype(np.float32)
+    rew = (rew / (np.float32(1) - rew)).astype(np.float32)
+    rew = (rew / np.sum(rew, dtype=np.float32)).astype(np.float32)
+    rew = (rew - np.mean(rew, dtype=np.float32)).astype(np.float32)
+    return np.broadcast_to(rew[:, None], (B, L)).copy()

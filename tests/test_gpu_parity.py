@@ -268,6 +268,36 @@ def test_get_reward_c1_full_vs_oracle(precision):
     assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
+@pytest.mark.parametrize("name", _cases.names("mali_reward"))
+def test_mali_reward(name, precision):
+    """tg.maligan.get_mali_reward (features once + tg_dis_rescore_dropout) against the reference's
+    get_mali_reward golden and the oracle; values are O(1/B), the tolerance is relative to that scale."""
+    c = _cases.load(name)
+    V, L, B, R = int(c["V"]), int(c["L"]), int(c["B"]), int(c["R"])
+    sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=int(c["dseed"]))
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), sd, DEV).train()
+    samples = synth.tokens(int(c["sseed"]), (B, L), V)
+    du = synth.uniform01(int(c["useed"]), (R, B, dis.feature_dim))
+    rew = tg.maligan.get_mali_reward(dis, _t(samples), R, dropout_uniforms=_t(du), precision=precision)
+    assert rew.is_cuda and tuple(rew.shape) == (B, L)
+    rew = rew.cpu().numpy()
+    np.testing.assert_allclose(rew, c["reward"], atol=1e-4 / B, rtol=1e-4)
+    np.testing.assert_allclose(rew, oracle.mali_reward(oracle.Dis(sd), samples, R, float(c["dropout_p"]), du),
+                               atol=1e-4 / B, rtol=1e-4)
+    # per-mask probabilities against R separate scorer passes with the same masks (the reference's loop)
+    feat = tg.ops.dis_score(dis, _t(samples), want_reward=False, want_feature=True, precision=precision)["feature"]
+    probs = tg.ops.dis_rescore_dropout(dis, feat, R, col=1, dropout_p=float(c["dropout_p"]), dropout_uniforms=_t(du))
+    for r in range(R):
+        one = tg.ops.dis_score(dis, _t(samples), col=1, dropout_p=float(c["dropout_p"]), dropout_uniforms=_t(du[r]),
+                               precision=precision)["reward"]
+        np.testing.assert_allclose(probs[r].cpu().numpy(), one.cpu().numpy(), atol=2e-6, rtol=0)
+    # eval mode: no dropout, every mask row equal
+    dis.eval()
+    ev = tg.maligan.get_mali_reward(dis, _t(samples), R)
+    assert torch.isfinite(ev).all() and abs(float(ev[:, 0].sum())) < 1e-6
+
+
 def test_errors_and_cpu_inputs():
     gen = tg.modules.synthetic_generator(100, 32, 32, 20, device=DEV)
     with pytest.raises(RuntimeError):

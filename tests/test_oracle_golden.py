@@ -99,3 +99,18 @@ def test_canonical_sampler_properties():
     # degenerate: u -> 1 picks the last valid entry, one-hot rows pick the hot entry
     p = np.zeros((3, 50), np.float32); p[0, 7] = 1; p[1, 49] = 1; p[2, 0] = 1
     assert oracle.sample_from_probs(p, np.array([0.5, 0.99999994, 0.0], np.float32)).tolist() == [7, 49, 0]
+
+
+@pytest.mark.parametrize("name", _cases.names("mali_reward"))
+def test_mali_reward_matches_reference(name):
+    """oracle.mali_reward against MaliGANInstructor.get_mali_reward run from the reference source
+    (tools/make_goldens_mali.py).  Values are O(1/B): the tolerance is relative to that scale."""
+    c = _cases.load(name)
+    V, L, B, R = int(c["V"]), int(c["L"]), int(c["B"]), int(c["R"])
+    od = oracle.Dis(synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=int(c["dseed"])))
+    samples = synth.tokens(int(c["sseed"]), (B, L), V)
+    du = synth.uniform01(int(c["useed"]), (R, B, od.F))
+    rew = oracle.mali_reward(od, samples, R, float(c["dropout_p"]), du)
+    assert rew.shape == (B, L)
+    np.testing.assert_allclose(rew, c["reward"], atol=1e-4 / B, rtol=1e-4)
+    assert np.array_equal(rew, np.broadcast_to(rew[:, :1], rew.shape))

@@ -16,7 +16,8 @@ MAX_OUT = 8
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
            "tg_dis_workspace_bytes",
-           "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_reward_reduce",
+           "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
+           "tg_reward_reduce",
            "tg_profile_enable", "tg_profile_read"]
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
@@ -67,6 +68,9 @@ def lib():
         l.tg_dis_score_rollout.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float] + [C.c_void_p] * 3 + \
                                           [C.c_size_t, C.c_void_p]
         l.tg_dis_score_rollout.restype = C.c_int
+        l.tg_dis_rescore_dropout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]
+        l.tg_dis_rescore_dropout.restype = C.c_int
         l.tg_reward_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
         l.tg_profile_enable.argtypes = [C.c_int]
         l.tg_profile_enable.restype = None

@@ -1414,6 +1414,112 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
 
 }  // namespace
 
+namespace {
+
+struct RescoreArgs {
+    const float* feature;   // [N,F]
+    const float* uniforms;  // [R,N,F] or null
+    const float* out_w;     // [n_out,F]
+    const float* out_b;
+    float* reward_out;      // [R,N]
+    int N, R, F, n_out, col;
+    float keep, scale;
+};
+
+// One workgroup per sample: the feature row and the output layer's columns stay in registers over the R masks.
+// Fixed summation order (thread-strided partials, xor tree, waves in order): bit-reproducible.
+constexpr int kRescorePer = 8;  // features per thread: F <= 256 * 8
+__global__ __launch_bounds__(256) void k_dis_rescore(const RescoreArgs a) {
+    __shared__ float red[4][kMaxOut];
+    const int nidx = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    float fv[kRescorePer], ow[kMaxOut][kRescorePer];
+#pragma unroll
+    for (int i = 0; i < kRescorePer; ++i) {
+        const int f = tid + 256 * i;
+        fv[i] = (f < a.F) ? a.feature[(size_t)nidx * a.F + f] : 0.f;
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) ow[o][i] = (f < a.F && o < a.n_out) ? a.out_w[(size_t)o * a.F + f] : 0.f;
+    }
+    for (int r = 0; r < a.R; ++r) {
+        float part[kMaxOut];
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o) part[o] = 0.f;
+        const float* u = a.uniforms ? a.uniforms + ((size_t)r * a.N + nidx) * a.F : nullptr;
+#pragma unroll
+        for (int i = 0; i < kRescorePer; ++i) {
+            const int f = tid + 256 * i;
+            float d = fv[i];
+            if (u) d = (f < a.F && u[f] < a.keep) ? d * a.scale : 0.f;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) part[o] = __builtin_fmaf(d, ow[o][i], part[o]);
+        }
+#pragma unroll
+        for (int o = 0; o < kMaxOut; ++o)
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) part[o] += __shfl_xor(part[o], off, 64);
+        __syncthreads();  // red is free again
+        if (lane == 0)
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) red[wv][o] = part[o];
+        __syncthreads();
+        if (tid == 0) {
+            float lg[kMaxOut], M = TG_NEG_INF;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) {
+                lg[o] = (o < a.n_out) ? a.out_b[o] + (((red[0][o] + red[1][o]) + red[2][o]) + red[3][o]) : TG_NEG_INF;
+                M = __builtin_fmaxf(M, lg[o]);
+            }
+            float S = 0.f, pick = 0.f;
+#pragma unroll
+            for (int o = 0; o < kMaxOut; ++o) {
+                const float e = tg_expf(lg[o] - M);
+                S += e;
+                pick = (o == a.col) ? e : pick;
+            }
+            a.reward_out[(size_t)r * a.N + nidx] = pick / S;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int tg_dis_rescore_dropout(const TgDisWeights* w, const float* feature, int N, int R, int col,
+                                      float dropout_p, const float* dropout_uniforms, float* reward_out,
+                                      void* stream) {
+    if (!w || !w->out_w || !w->out_b || !feature || !reward_out || N < 0 || R < 1) {
+        tg_set_error("tg_dis_rescore_dropout: bad arguments (N=%d R=%d)", N, R);
+        return TG_ERR_ARG;
+    }
+    if (w->F < 1 || w->F > 256 * kRescorePer || w->n_out < 1 || w->n_out > kMaxOut || col < 0 || col >= w->n_out) {
+        tg_set_error("tg_dis_rescore_dropout: F=%d (max %d), n_out=%d, column %d out of range", w->F,
+                     256 * kRescorePer, w->n_out, col);
+        return TG_ERR_ARG;
+    }
+    if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && !dropout_uniforms)) {
+        tg_set_error("tg_dis_rescore_dropout: dropout_p=%g needs uniforms and must be in [0,1)", (double)dropout_p);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    RescoreArgs a = {};
+    a.feature = feature;
+    a.uniforms = dropout_p > 0.f ? dropout_uniforms : nullptr;
+    a.out_w = w->out_w;
+    a.out_b = w->out_b;
+    a.reward_out = reward_out;
+    a.N = N; a.R = R; a.F = w->F; a.n_out = w->n_out; a.col = col;
+    a.keep = 1.f - dropout_p;
+    a.scale = 1.f / (1.f - dropout_p);
+    tg_prof_begin(TG_KERNEL_DIS_FINAL, (hipStream_t)stream);
+    hipLaunchKernelGGL(k_dis_rescore, dim3(N), dim3(256), 0, (hipStream_t)stream, a);
+    tg_prof_end((hipStream_t)stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        tg_set_error("k_dis_rescore launch: %s", hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    return TG_OK;
+}
+
 extern "C" size_t tg_dis_workspace_bytes(const TgDisWeights* w, int N, int L) {
     if (!w || N < 1) return 0;
     return ws_bytes(w, N, L, 0);

@@ -129,3 +129,21 @@ def reward_reduce(raw, B, L, R):
     _lib.check(_lib.lib().tg_reward_reduce(_lib.dev_ptr(raw, F32, "raw"), B, L, R, _lib.dev_ptr(out),
                                            _lib.stream_ptr()))
     return out
+
+
+def dis_rescore_dropout(dis, feature, R, col=1, dropout_p=0.0, dropout_uniforms=None, weights=None):
+    """tg_dis_rescore_dropout: R dropout masks + output layer + softmax column over precomputed highway features
+    (the loop of MaliGANInstructor.get_mali_reward, instructor/real_data/maligan_instructor.py:142-147).
+    feature [N,F]; dropout_uniforms [R,N,F]; returns [R,N]."""
+    w, keep = weights if weights is not None else _lib.dis_weights(dis)
+    N = feature.shape[0]
+    if feature.dim() != 2 or feature.shape[1] != w.F:
+        raise RuntimeError("textgan_hip: feature must be [N, %d]" % w.F)
+    if dropout_p > 0.0 and (dropout_uniforms is None or dropout_uniforms.numel() != R * N * w.F):
+        raise RuntimeError("textgan_hip: dropout_uniforms must have R*N*F = %d elements" % (R * N * w.F))
+    out = torch.empty(R, N, dtype=F32, device=feature.device)
+    _lib.check(_lib.lib().tg_dis_rescore_dropout(
+        C.byref(w), _lib.dev_ptr(feature, F32, "feature"), N, R, col, float(dropout_p),
+        _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms") if dropout_p > 0.0 else None,
+        _lib.dev_ptr(out), _lib.stream_ptr()))
+    return out
