@@ -268,6 +268,43 @@ def test_get_reward_c1_full_vs_oracle(precision):
     assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
 
 
+def test_get_reward_c2_full_size_properties():
+    """BASELINE config 2 at full size (V5255 L51 E=H=32 B64 R16, 52 224 completions, live dropout): properties that
+    do not need the oracle.  Determinism, the sentence rows, probabilities, sharding by rollout index (each shard
+    computed on its own equals the unsharded call bit for bit), prefix copy, and the reduce's closed form."""
+    V, L, B, R = 5255, 51, 64, 16
+    gen = tg.modules.synthetic_generator(V, 32, 32, L, seed=0, std=1.0, device=DEV)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=DEV).train()
+    sent = _t(synth.tokens(1, (B, L), V))
+    g = torch.Generator(device=DEV)
+    g.manual_seed(7)
+    u = torch.rand(R, L, L, B, device=DEV, generator=g)
+    du = torch.rand(R * L, B, dis.feature_dim, device=DEV, generator=g)
+    ro = tg.ROLLOUT(gen)
+    rew, raw, comp = ro.get_reward(sent, R, dis, uniforms=u, dropout_uniforms=du, return_parts=True)
+    rew2, raw2, comp2 = ro.get_reward(sent, R, dis, uniforms=u, dropout_uniforms=du, return_parts=True)
+    assert torch.equal(comp, comp2) and torch.equal(raw, raw2) and torch.equal(rew, rew2)
+    assert tuple(comp.shape) == (R, L, B, L) and int(comp.min()) >= 0 and int(comp.max()) < V
+    for gnum in (1, 17, L):  # the first given_num tokens are the sentence's
+        assert torch.equal(comp[:, gnum - 1, :, :gnum], sent[:, :gnum].expand(R, B, gnum))
+    assert bool(((raw >= 0) & (raw <= 1)).all())
+    np.testing.assert_allclose(rew.cpu().numpy(), raw.cpu().numpy().reshape(B, L, R).mean(-1), atol=1e-6, rtol=0)
+    # shards of the rollout index, each on its own, against the unsharded completions / raw rows
+    for lo, hi in ((0, 4), (4, 5), (5, 16)):
+        part = torch.full_like(comp, -1)
+        tg.ops.gen_rollout(gen, sent, R, u, i_lo=lo, i_hi=hi, out=part)
+        assert torch.equal(part[lo:hi], comp[lo:hi]) and bool((part[:lo] == -1).all()) and bool((part[hi:] == -1).all())
+        dshard = du.view(R, L * B * dis.feature_dim)[lo:hi].reshape((hi - lo) * L * B, dis.feature_dim)
+        r = tg.ops.dis_score_rollout(dis, sent, comp[lo:hi].contiguous(), col=1, dropout_p=float(dis.dropout.p),
+                                     dropout_uniforms=dshard.contiguous())
+        assert torch.equal(r, raw[lo * L:hi * L])
+    # eval mode: the g = L rows score the sentence itself and cannot depend on the rollout index
+    dis.eval()
+    _, raw_e, _ = ro.get_reward(sent, R, dis, uniforms=u, return_parts=True)
+    rw = raw_e.view(R, L, B)
+    assert torch.equal(rw[:, L - 1], rw[0, L - 1].expand(R, B))
+
+
 @pytest.mark.parametrize("precision", ["fp32", "split_f16"])
 @pytest.mark.parametrize("name", _cases.names("mali_reward"))
 def test_mali_reward(name, precision):
