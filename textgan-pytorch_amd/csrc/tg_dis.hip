@@ -98,28 +98,48 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     const int hh = lane >> 5;
     const int seq0 = blockIdx.x * S;
 
-    // ---- gather: token embeddings -> LDS, time-major [t][s][68]
-    for (int idx = tid; idx < L * S * (kEd / 4); idx += kConvThreads) {
-        const int c = idx & 15;           // 16-B chunk of the 256-B row
-        const int ts = idx >> 4;          // t*S + s
-        const int s = ts & (S - 1), t = ts >> log2S;
-        const int seq = tg_min(seq0 + s, a.N - 1);
-        int tok = (int)a.seqs[(size_t)seq * L + t];
-        tok = tg_min(tg_max(tok, 0), a.w.V - 1);
-        const f32x4 v = *reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tok * kEd + 4 * c);
-        if (!SPLIT) {
-            *reinterpret_cast<f32x4*>(ebuf + (size_t)ts * kERow + 4 * c) = v;
-        } else {
-            const float sc = a.scales[1];
-            f16x4 h, l;
+    // ---- gather: token embeddings -> LDS, time-major [t][s][68].  Eight 16-B pieces per thread and pass, all token
+    // reads first and all embedding reads next: two memory round trips per pass instead of two per piece.
+    {
+        constexpr int kGB = 8;
+        const int total = L * S * (kEd / 4);
+        const float sc = SPLIT ? a.scales[1] : 1.f;
+        for (int base = tid; base < total; base += kConvThreads * kGB) {
+            int tok[kGB];
+            f32x4 v[kGB];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = v[e] * sc;
-                h[e] = (_Float16)x;
-                l[e] = (_Float16)(x - (float)h[e]);
+            for (int j = 0; j < kGB; ++j) {
+                const int idx = tg_min(base + kConvThreads * j, total - 1);
+                const int ts = idx >> 4;          // t*S + s
+                const int sq = ts & (S - 1), t = ts >> log2S;
+                const int seq = tg_min(seq0 + sq, a.N - 1);
+                tok[j] = (int)a.seqs[(size_t)seq * L + t];
             }
-            *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + 4 * c) = h;
-            *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + kEd + 4 * c) = l;
+#pragma unroll
+            for (int j = 0; j < kGB; ++j) {
+                const int c = (base + kConvThreads * j) & 15;  // 16-B chunk of the 256-B row
+                const int tk = tg_min(tg_max(tok[j], 0), a.w.V - 1);
+                v[j] = *reinterpret_cast<const f32x4*>(a.w.emb + (size_t)tk * kEd + 4 * c);
+            }
+#pragma unroll
+            for (int j = 0; j < kGB; ++j) {
+                const int idx = base + kConvThreads * j;
+                if (idx >= total) continue;
+                const int c = idx & 15, ts = idx >> 4;
+                if (!SPLIT) {
+                    *reinterpret_cast<f32x4*>(ebuf + (size_t)ts * kERow + 4 * c) = v[j];
+                } else {
+                    f16x4 h, l;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float x = v[j][e] * sc;
+                        h[e] = (_Float16)x;
+                        l[e] = (_Float16)(x - (float)h[e]);
+                    }
+                    *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + 4 * c) = h;
+                    *reinterpret_cast<f16x4*>(ebuf_h + (size_t)ts * kERowH + kEd + 4 * c) = l;
+                }
+            }
         }
     }
     // zero rows behind the sequence: a merged tile's wider members read past position L - 1 against zero weights
