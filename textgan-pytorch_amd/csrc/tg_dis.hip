@@ -844,15 +844,18 @@ void k_dis_highway_split(const HsArgs a) {
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv / WS, wn = wv % WS;
     const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
-    // Workgroups go to the 8 XCDs round-robin by blockIdx.  XCD x takes the sequence tiles bm = x (mod 8) and walks
-    // all feature chunks of one tile before the next, so the workgroups resident on an XCD together share operands
-    // inside that XCD's L2 as far as their phases allow.
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int bn = jx % a.h.nchunk, bm = (jx / a.h.nchunk) * 8 + xcd;
-    if (bm >= a.h.nseqtile) return;
-    const int f0 = bn * TF, s0 = bm * TS;
+    // Persistent workgroups, dealt to the 8 XCDs round-robin by blockIdx.  XCD x owns the sequence tiles bm = x (mod 8)
+    // and its workgroups walk that list -- all feature chunks of a tile, then the next tile -- in strides of the
+    // XCD's workgroup count.  Every tile costs the same, so the workgroups of an XCD stay within a k-step or two of
+    // each other and the operand slices they share (a pooled tile 14 ways, a W_hw slab ~4 ways) are served by that
+    // XCD's L2; dispatched one tile per workgroup they drift apart and the L2 thrashes (6.7 GB fetched per launch).
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int njx = ((a.h.nseqtile - xcd + 7) >> 3) * a.h.nchunk;  // work items of this XCD
     const size_t wlo = (size_t)F * F;
     const float sp = a.scales[1];
+    for (int jx = slot; jx < njx; jx += nslot) {
+    const int bn = jx % a.h.nchunk, bm = (jx / a.h.nchunk) * 8 + xcd;
+    const int f0 = bn * TF, s0 = bm * TS;
 
     f32x16 acc[2][NJ];
 #pragma unroll
@@ -912,6 +915,7 @@ void k_dis_highway_split(const HsArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
     __syncthreads();  // the last tile's reads are done before the epilogue reuses the space
     hw_epilogue_rows<NJ, TF, TS, NT>(a.h, acc, reinterpret_cast<float*>(tiles), f0, s0, bn, wm, wn, n, hh, tid);
+    }
 }
 
 template <int NJ, int TS, class ARGS>
@@ -1293,8 +1297,15 @@ int launch_highway_split(HsArgs& hs, hipStream_t stream) {
     hs.h.nchunk = (hs.h.w.F + TF - 1) / TF;
     hs.h.nseqtile = (hs.h.N + TS - 1) / TS;
     tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
-    hipLaunchKernelGGL((k_dis_highway_split<WF, WS, NJ>), dim3(8 * ((hs.h.nseqtile + 7) / 8) * hs.h.nchunk),
-                       dim3(64 * WF * WS), sm, stream, hs);
+    // persistent: as many workgroups as are resident at once (sm bytes of LDS each), a multiple of the 8 XCDs
+    int dev = 0, ncu = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    const int per_cu = (int)((160 * 1024) / sm) > 0 ? (int)((160 * 1024) / sm) : 1;
+    const long total = (long)hs.h.nseqtile * hs.h.nchunk;
+    long grid = (long)ncu * per_cu;
+    if (grid > total) grid = total;
+    grid = (grid + 7) / 8 * 8;
+    hipLaunchKernelGGL((k_dis_highway_split<WF, WS, NJ>), dim3((unsigned)grid), dim3(64 * WF * WS), sm, stream, hs);
     tg_prof_end(stream);
     return TG_OK;
 }
