@@ -112,8 +112,13 @@ __device__ __forceinline__ void load16(const float* p, float (&dst)[16]) {
 
 __device__ __forceinline__ int clamp_tok(int64_t t, int V) { return tg_min(tg_max((int)t, 0), V - 1); }
 
-template <bool SAMPLE, int HT, bool REG, bool SPLIT>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_gen(const GenArgs a) {
+// WPE = waves per SIMD the kernel is built for: 2 (256 VGPRs) or, for the split kernel on grids that fill the chip
+// three times over, 3 (168 VGPRs: gate weights re-read per step, two A fragments in flight instead of three).
+template <bool SAMPLE, int HT, bool REG, bool SPLIT, int WPE = 2>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+void k_gen(const GenArgs a) {
+    static_assert(WPE == 2 || (WPE == 3 && SPLIT), "three waves per SIMD: split kernel only");
+    constexpr bool kLean = WPE == 3;
     static_assert(!SPLIT || (SAMPLE && REG), "the split-fp16 projection exists for the E = H = 32 sampling kernel");
     constexpr int kH = 32 * HT;
     constexpr int kHStride = kH + 4;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
@@ -130,7 +135,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     float* Mbuf = reinterpret_cast<float*>(selv + kRows);              // [32] row max
     double* selp = reinterpret_cast<double*>(Mbuf + kRows);            // [32] prefix before the group
     double* tgt = selp + kRows;                                        // [32] target = u*S
-    float* wbuf = reinterpret_cast<float*>(tgt + kRows);               // [32][EG+1] recomputed weights
+    float* gbl = reinterpret_cast<float*>(tgt + kRows);                // [128] b_ih + b_hh (lean kernel only)
+    float* wbuf = gbl + (kLean ? 4 * kH : 0);                           // [32][EG+1] recomputed weights
     float* xbuf = wbuf;                                                // !REG: [32][E+4] step inputs (aliases wbuf/rec)
     const int EG = a.geo.GK * 16;
     float2* rec = reinterpret_cast<float2*>(wbuf + kRows * (EG + 1));  // [NG][8][32] (32*(EG+1) is even)
@@ -198,9 +204,13 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
     // ------------------------------------------------------------------ resident weights (REG)
     // gate tile T covers hidden units [8T, 8T+8): tile row i -> gate i>>3, unit 8T + (i&7), so that
     // D reg r of lane (n, hh) is gate r>>2 of unit 8T + 4hh + (r&3): i,f,g,o of a unit share a lane.
+    // The lean kernel (three waves per SIMD, 168 VGPRs) re-reads its gate weights (L2-resident) at every step and
+    // keeps the summed gate bias in LDS instead of holding 48 registers through the projection.
     float wih[16], whh[16];
     f32x16 gbias;
-    if constexpr (REG) {
+    if constexpr (kLean) {
+        if (tid < 4 * kH) gbl[tid] = a.w.b_ih[tid] + a.w.b_hh[tid];
+    } else if constexpr (REG) {
         const int i = lane & 31;
         const int grow = (i >> 3) * kH + 8 * w + (i & 7);
         load16(a.w.w_ih + (size_t)grow * 32 + 16 * hh, wih);
@@ -244,6 +254,21 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
         if constexpr (REG) {
             float xb[16];
             load16(a.w.emb + (size_t)tok * 32 + 16 * hh, xb);
+            if constexpr (kLean) {
+                const float* pih = a.w.w_ih;
+                const float* phh = a.w.w_hh;
+                asm volatile("" : "+s"(pih), "+s"(phh));  // keeps the loads inside the step loop
+                const int i = lane & 31;
+                const int grow = (i >> 3) * kH + 8 * w + (i & 7);
+                load16(pih + (size_t)grow * 32 + 16 * hh, wih);
+                load16(phh + (size_t)grow * kH + 16 * hh, whh);
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(gbl + q4 * kH + 8 * w + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) gbias[4 * q4 + e] = b4[e];
+                }
+            }
             f32x16 acc = gbias;
 #pragma unroll
             for (int j = 0; j < 16; ++j) acc = TG_MFMA32(wih[j], xb[j], acc);
@@ -518,7 +543,25 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(2, 2))
                             }
                         }
                     };
-                    if (nfull > 0) {
+                    if constexpr (kLean) {
+                        // two fragments in flight (coalesced 1-KiB loads, three waves per SIMD to cover them)
+                        AFrag s0, s1;
+                        f32x16 acc0, acc1;
+                        load_a(0, s0);
+                        if (nfull > 1) load_a(1, s1);
+                        acc0 = mfma_tile(0, s0);
+                        if (nfull > 2) load_a(2, s0);
+                        int q = 0;
+                        // invariant at loop head: acc0 = tile q (q even), s1 = tile q+1, s0 = tile q+2 in flight
+                        for (; q + 2 < nfull; q += 2) {
+                            acc1 = mfma_tile(q + 1, s1); softmax_tile(acc0, q); interleave();
+                            if (q + 3 < nfull) load_a(q + 3, s1);
+                            acc0 = mfma_tile(q + 2, s0); softmax_tile(acc1, q + 1); interleave();
+                            if (q + 4 < nfull) load_a(q + 4, s0);
+                        }
+                        softmax_tile(acc0, q);
+                        if (q + 1 < nfull) { acc1 = mfma_tile(q + 1, s1); softmax_tile(acc1, q + 1); }
+                    } else if (nfull > 0) {
                         // A fragments are fetched three tiles ahead (an L2 round trip under load is ~2 tiles long)
                         AFrag a0, a1, a2;
                         f32x16 acc0, acc1;
@@ -897,8 +940,8 @@ int prepare_split(GenArgs& a, void* scratch, hipStream_t stream) {
     return TG_OK;
 }
 
-size_t smem_bytes(const SamplerGeom& g, bool sample, int E, int H) {
-    size_t b = sizeof(float) * kRows * (H + 4) + sizeof(float) * kNSpan * kRows + sizeof(double) * kNSpan * kRows +
+size_t smem_bytes(const SamplerGeom& g, bool sample, int E, int H, bool lean = false) {
+    size_t b = (lean ? sizeof(float) * 4 * H : 0) + sizeof(float) * kRows * (H + 4) + sizeof(float) * kNSpan * kRows + sizeof(double) * kNSpan * kRows +
                sizeof(int) * kRows * 2 + sizeof(float) * kRows + sizeof(double) * kRows * 2;
     size_t region = 16;
     if (sample) {
@@ -925,9 +968,9 @@ int check_weights(const TgGenWeights* w) {
     return TG_OK;
 }
 
-template <bool SAMPLE, int HT, bool REG, bool SPLIT = false>
+template <bool SAMPLE, int HT, bool REG, bool SPLIT = false, int WPE = 2>
 int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
-    size_t sm = smem_bytes(a.geo, SAMPLE, a.w.E, a.w.H);
+    size_t sm = smem_bytes(a.geo, SAMPLE, a.w.E, a.w.H, WPE == 3);
     if (sm > 160 * 1024) {
         tg_set_error("generator kernel needs %zu bytes of LDS (> 160 KiB) for V=%d E=%d H=%d", sm, a.w.V, a.w.E,
                      a.w.H);
@@ -935,7 +978,7 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
     }
     static thread_local size_t set_max = 0;
     if (sm > 48 * 1024 && sm > set_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG, SPLIT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG, SPLIT, WPE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
         if (e != hipSuccess) {
             tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -944,7 +987,7 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
         set_max = sm;
     }
     tg_prof_begin(SAMPLE ? TG_KERNEL_GEN_SAMPLE : TG_KERNEL_GEN_TEACHER, stream);
-    hipLaunchKernelGGL((k_gen<SAMPLE, HT, REG, SPLIT>), dim3(grid), dim3(kThreads), sm, stream, a);
+    hipLaunchKernelGGL((k_gen<SAMPLE, HT, REG, SPLIT, WPE>), dim3(grid), dim3(kThreads), sm, stream, a);
     tg_prof_end(stream);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
@@ -957,7 +1000,9 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
 template <bool SAMPLE>
 int launch(const GenArgs& a, int grid, hipStream_t stream) {
     if constexpr (SAMPLE) {
-        if (a.frag) return launch_t<true, 1, true, true>(a, grid, stream);
+        // three workgroups per CU pay off once the grid fills them (4 waves x 3 on each of 256 CUs)
+        if (a.frag) return grid >= 3 * 256 * 2 ? launch_t<true, 1, true, true, 3>(a, grid, stream)
+                                               : launch_t<true, 1, true, true, 2>(a, grid, stream);
     }
     if (is_reg(a.w.E, a.w.H)) return launch_t<SAMPLE, 1, true>(a, grid, stream);
     switch (a.w.H) {
