@@ -263,7 +263,11 @@ def main():
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peaks[dom],
                          "unit": "TFLOP/s", "frac": ach / peaks[dom],
                          "traffic": pmc_traffic(args.workload, dom) if world == 1 else None,
-                         "flops_per_launch": per_launch[dom], "avg_launch_ms": kernels[dom]["avg_ms"]},
+                         "flops_per_launch": per_launch[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
+                         # split-f16 kernels issue 3 fp16 MFMA products per algorithmic multiply-add: the share of the
+                         # fp16 peak the matrix pipes actually deliver (the kernel is power-limited)
+                         "mfma_products_per_flop": issue_factor[dom],
+                         "issued_frac": ach * issue_factor[dom] / peaks[dom]},
             "kernels": kernels,
         }
         if not args.no_cpu_baseline and world == 1:
