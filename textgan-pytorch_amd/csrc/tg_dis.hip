@@ -398,13 +398,24 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 }
 
 // ---- split-fp16 preparation: |max| of a tensor, power-of-two scales, (hi, lo) halves of the conv weights
+// One atomic per workgroup: thousands of same-address atomics serialise (~20 ns each) and were most of this kernel.
+__device__ __forceinline__ void block_atomic_max(unsigned m, unsigned* out) {
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m) atomicMax(out, m);
+    }
+}
+
 __global__ __launch_bounds__(256) void k_absmax(const float* x, size_t n, unsigned* out) {
     unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);  // |x| as ordered bits (NaN sorts high: scale 1 below)
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    block_atomic_max(m, out);
 }
 
 __global__ void k_make_scales(const unsigned* absmax, float* scales) {
@@ -511,9 +522,7 @@ __global__ __launch_bounds__(256) void k_absmax_banks(const SplitArgs a, unsigne
     unsigned m = 0;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256)
         m = max(m, __float_as_uint(a.src[k][i]) & 0x7fffffffu);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    block_atomic_max(m, out);
 }
 
 __global__ __launch_bounds__(256) void k_split(const float* src, size_t n, _Float16* hi, _Float16* lo,
@@ -1266,7 +1275,7 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     hipLaunchKernelGGL(k_absmax_banks, dim3(tg_min_host((maxelems + 255) / 256, 64), w->n_filters), dim3(256), 0, stream,
                        sa, absmax);
     const size_t ne = (size_t)w->V * kEd;
-    hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 512)), dim3(256), 0, stream, w->emb, ne,
+    hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 256)), dim3(256), 0, stream, w->emb, ne,
                        absmax + 1);
     hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
     sa.w16 = w16;
@@ -1401,7 +1410,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         float* scales = (float*)((char*)scal + 16) + 4;
         const size_t nw = (size_t)w->F * w->F;
         tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
-        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 1024)), dim3(256), 0, stream, w->hw_w, nw,
+        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 512)), dim3(256), 0, stream, w->hw_w, nw,
                            absmax);
         hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
         hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((nw / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,

@@ -832,9 +832,15 @@ __global__ __launch_bounds__(256) void k_gen_absmax(const float* x, size_t n, un
     unsigned m = 0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);  // |x| as ordered bits
+    __shared__ unsigned red[4];  // one atomic per workgroup: same-address atomics serialise
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m) atomicMax(out, m);
+    }
 }
 
 __device__ __forceinline__ unsigned short tg_bf16_rn(float x) {  // round to nearest even; x finite
@@ -932,7 +938,7 @@ int prepare_split(GenArgs& a, void* scratch, hipStream_t stream) {
     }
     const size_t n = (size_t)a.w.V * 32;
     const int blocks = (int)((n + 1023) / 1024);
-    hipLaunchKernelGGL(k_gen_absmax, dim3(blocks < 1024 ? blocks : 1024), dim3(256), 0, stream, a.w.w_out, n, absmax);
+    hipLaunchKernelGGL(k_gen_absmax, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, stream, a.w.w_out, n, absmax);
     hipLaunchKernelGGL(k_gen_make_frag, dim3(a.geo.NT, 4), dim3(64), 0, stream, a.w.w_out, a.w.b_out, a.w.V, a.geo.Ls,
                        a.geo.NT, absmax, gscale, frag);
     a.frag = frag;
