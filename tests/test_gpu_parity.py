@@ -268,6 +268,40 @@ def test_get_reward_c1_full_vs_oracle(precision):
     assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
 
 
+@pytest.mark.parametrize("std,bias_scale", [(0.01, 1.0), (4.0, 1.0), (1.0, 50.0), (1e-4, 1e-3)])
+def test_generator_split_precision_across_weight_scales(std, bias_scale):
+    """The split projection scales its operands by a power of two taken from |max|: token parity with the oracle has
+    to hold for tiny, large and bias-dominated output layers alike."""
+    V, L, B, R = 5000, 20, 64, 2
+    gsd = {k: np.array(v) for k, v in synth.gen_state(V, 32, 32, seed=3, std=std).items()}
+    gsd["lstm2out.bias"] = (gsd["lstm2out.bias"] * bias_scale).astype(np.float32)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    sent, u = synth.tokens(1, (B, L), V), synth.uniform01(2, (R, L, L, B))
+    og = oracle.Gen(gsd)
+    ref = oracle.gen_rollout(og, sent, R, u)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision="split_f16").cpu().numpy()
+    _cases.check_token_parity(replay, ref, u, og, max_check=50)
+
+
+@pytest.mark.parametrize("conv_scale,emb_scale", [(1e-3, 1.0), (1e3, 1.0), (1.0, 1e-3), (30.0, 30.0)])
+def test_scorer_split_precision_across_weight_scales(conv_scale, emb_scale):
+    V, L, N = 5000, 20, 512
+    sd = {k: np.array(v) for k, v in synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=5).items()}
+    for k in sd:
+        if k.startswith("convs") and k.endswith("weight"):
+            sd[k] = (sd[k] * conv_scale).astype(np.float32)
+    sd["embeddings.weight"] = (sd["embeddings.weight"] * emb_scale).astype(np.float32)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), sd, DEV).eval()
+    seqs = synth.tokens(7, (N, L), V)
+    a = tg.ops.dis_score(dis, _t(seqs), want_feature=True, precision="fp32")
+    b = tg.ops.dis_score(dis, _t(seqs), want_feature=True, precision="split_f16")
+    o = oracle.dis_forward(oracle.Dis(sd), seqs, col=1, want_feature=True)
+    scale = float(a["feature"].abs().max())
+    assert float((a["feature"] - b["feature"]).abs().max()) <= 3e-5 * scale
+    assert np.abs(b["feature"].cpu().numpy() - o["feature"]).max() <= 3e-5 * scale
+    np.testing.assert_allclose(b["reward"].cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
+
+
 def test_get_reward_c2_full_size_properties():
     """BASELINE config 2 at full size (V5255 L51 E=H=32 B64 R16, 52 224 completions, live dropout): properties that
     do not need the oracle.  Determinism, the sentence rows, probabilities, sharding by rollout index (each shard
