@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
     ap.add_argument("--dis-precision", default=None, choices=["fp32", "split_f16"],
                     help="scorer conv/highway arithmetic (default: the library default, split_f16)")
+    ap.add_argument("--dropout-rng", default=None, choices=["kernel", "torch"],
+                    help="scorer dropout masks: counter-based inside the kernel (default) or torch.rand uniforms")
     ap.add_argument("--gen-precision", default=None, choices=["fp32", "split_f16"],
                     help="generator vocabulary-projection arithmetic (default: the library default, split_f16)")
     args = ap.parse_args()
@@ -188,6 +190,8 @@ def main():
         ro.generator.manual_seed(1234 + rank + 100 * gi)
         ro.dis_precision = args.dis_precision
         ro.gen_precision = args.gen_precision
+        if args.dropout_rng:
+            ro.dropout_rng = args.dropout_rng
         ros.append(ro)
 
     def step():

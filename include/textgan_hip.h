@@ -75,6 +75,11 @@ typedef struct TgDisWeights {
     int32_t n_filters;                    /* number of widths        */
     int32_t V, Ed, F, n_out;
     int32_t precision;                    /* TG_DIS_FP32 or TG_DIS_SPLIT_F16 (conv + highway)   */
+    uint32_t dropout_seed;                /* used when dropout_p > 0 and dropout_uniforms == NULL:
+                                           * element (n, f) of the call is kept iff
+                                           * hash32(n*F + f + seed*0x9E3779B9) < (1-p)*2^32 (lowbias32
+                                           * finaliser, tg_common.h) -- no [N,F] tensor of uniforms
+                                           * is materialised.  Vary the seed between calls.      */
 } TgDisWeights;
 
 /* Arithmetic of the scorer's convolutions and highway GEMM (gate, dropout, output layer, softmax: always fp32):
@@ -165,6 +170,9 @@ int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
  *   seqs             [N,L]      int64
  *   col                         softmax column (current_k + 1)
  *   dropout_p                   0 = eval mode (identity)
+ *   dropout_uniforms [N,F] fp32 or NULL: explicit U[0,1) draws (keep iff u < 1-p);
+ *                               NULL with dropout_p > 0 = counter-based masks from
+ *                               TgDisWeights.dropout_seed
  *   dropout_uniforms [N,F]      or NULL; keep = u < 1-p, scale 1/(1-p)
  *                               (nn.Dropout, discriminator.py:36,47)
  *   reward_out       [N]        or NULL

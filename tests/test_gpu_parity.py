@@ -302,6 +302,55 @@ def test_scorer_split_precision_across_weight_scales(conv_scale, emb_scale):
     np.testing.assert_allclose(b["reward"].cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
 
 
+def _hash32(x):
+    x = x.astype(np.uint64)
+    m = np.uint64(0xffffffff)
+    x ^= x >> np.uint64(16); x = (x * np.uint64(0x7feb352d)) & m
+    x ^= x >> np.uint64(15); x = (x * np.uint64(0x846ca68b)) & m
+    x ^= x >> np.uint64(16)
+    return x
+
+
+def test_counter_based_dropout_masks():
+    """dropout_uniforms = None: the masks come from tg_hash32(n*F + f + seed*0x9E3779B9) < (1-p)*2^32 inside the
+    highway epilogue.  The same masks rebuilt in numpy and fed to the oracle as 0/1 "uniforms" must give the same
+    logits; the keep rate is 1-p; a seed repeats, another seed differs; the MaliGAN re-scoring indexes (r, n, f)."""
+    V, L, N, p, seed = 300, 20, 333, 0.25, 0xC0FFEE
+    sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=9)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), sd, DEV)
+    od = oracle.Dis(sd)
+    F = od.F
+    seqs = synth.tokens(3, (N, L), V)
+    idx = (np.arange(N, dtype=np.uint64)[:, None] * np.uint64(F) + np.arange(F, dtype=np.uint64)[None, :])
+    keep = _hash32((idx + np.uint64(seed) * np.uint64(0x9E3779B9)) & np.uint64(0xffffffff)) < np.uint64(int((1 - p) * 2 ** 32))
+    assert abs(keep.mean() - (1 - p)) < 5e-3
+    for precision in ("fp32", "split_f16"):
+        r = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=p, want_logits=True, dropout_seed=seed, precision=precision)
+        o = oracle.dis_forward(od, seqs, col=1, dropout_p=p, dropout_uniforms=np.where(keep, 0.0, 1.0).astype(np.float32))
+        np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-4, atol=5e-6)
+        again = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=p, dropout_seed=seed, precision=precision)["reward"]
+        other = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=p, dropout_seed=seed + 1, precision=precision)["reward"]
+        assert torch.equal(again, r["reward"]) and not torch.equal(other, r["reward"])
+    R = 3
+    feat = tg.ops.dis_score(dis, _t(seqs), want_reward=False, want_feature=True, precision="fp32")["feature"]
+    probs = tg.ops.dis_rescore_dropout(dis, feat, R, col=1, dropout_p=p, dropout_seed=seed).cpu().numpy()
+    idx3 = (np.arange(R * N, dtype=np.uint64)[:, None] * np.uint64(F) + np.arange(F, dtype=np.uint64)[None, :])
+    keep3 = _hash32((idx3 + np.uint64(seed) * np.uint64(0x9E3779B9)) & np.uint64(0xffffffff)) < np.uint64(int((1 - p) * 2 ** 32))
+    u3 = np.where(keep3, 0.0, 1.0).astype(np.float32).reshape(R, N, F)
+    ref = tg.ops.dis_rescore_dropout(dis, feat, R, col=1, dropout_p=p, dropout_uniforms=_t(u3)).cpu().numpy()
+    np.testing.assert_array_equal(probs, ref)
+    # the drop-in draws a fresh seed per call: two get_reward calls with live dropout differ, eval mode does not
+    gen = tg.modules.synthetic_generator(V, 32, 32, L, seed=1, std=0.3, device=DEV)
+    sent = _t(synth.tokens(4, (8, L), V))
+    u = torch.rand(2, L, L, 8, device=DEV)
+    ro = tg.ROLLOUT(gen)
+    a1 = ro.get_reward(sent, 2, dis.train(), uniforms=u)
+    a2 = ro.get_reward(sent, 2, dis, uniforms=u)
+    assert not torch.equal(a1, a2) and float((a1 - a2).abs().max()) < 0.5
+    e1 = ro.get_reward(sent, 2, dis.eval(), uniforms=u)
+    assert torch.equal(e1, ro.get_reward(sent, 2, dis, uniforms=u))
+
+
 def test_get_reward_c2_full_size_properties():
     """BASELINE config 2 at full size (V5255 L51 E=H=32 B64 R16, 52 224 completions, live dropout): properties that
     do not need the oracle.  Determinism, the sentence rows, probabilities, sharding by rollout index (each shard

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_header():
     # 7 pointers + 4 int32 / see TgDisWeights in include/textgan_hip.h
     assert ctypes.sizeof(tg._lib.GenW) == 7 * 8 + 16
-    assert ctypes.sizeof(tg._lib.DisW) == 8 + 2 * 16 * 8 + 4 * 8 + 2 * 16 * 4 + 6 * 4
+    assert ctypes.sizeof(tg._lib.DisW) == 8 + 2 * 16 * 8 + 4 * 8 + 2 * 16 * 4 + 7 * 4 + 4  # 7 ints + tail padding
 
 
 def test_no_cpu_fallback():

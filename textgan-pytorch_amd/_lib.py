@@ -33,7 +33,8 @@ class DisW(C.Structure):
     _fields_ = [("emb", C.c_void_p), ("conv_w", C.c_void_p * MAX_FILTERS), ("conv_b", C.c_void_p * MAX_FILTERS),
                 ("hw_w", C.c_void_p), ("hw_b", C.c_void_p), ("out_w", C.c_void_p), ("out_b", C.c_void_p),
                 ("f", C.c_int32 * MAX_FILTERS), ("n", C.c_int32 * MAX_FILTERS), ("n_filters", C.c_int32),
-                ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("precision", C.c_int32)]
+                ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("precision", C.c_int32),
+                ("dropout_seed", C.c_uint32)]
 
 
 _lib = None
@@ -186,3 +187,18 @@ def profile_read():
         check(lib().tg_profile_read(kid, C.byref(ms), C.byref(n)))
         out[name] = (ms.value, n.value)
     return out
+
+
+_seed_state = {"base": None, "count": 0}
+
+
+def next_dropout_seed(rank=0):
+    """A fresh 32-bit seed for the scorer's counter-based dropout masks (TgDisWeights.dropout_seed): derived from
+    torch's CPU seed at first use (so torch.manual_seed makes runs repeatable), a call counter and the rank."""
+    if _seed_state["base"] is None:
+        _seed_state["base"] = int(torch.initial_seed()) & 0xffffffffffffffff
+    _seed_state["count"] += 1
+    x = (_seed_state["base"] + 0x9E3779B97F4A7C15 * (_seed_state["count"] + (rank << 40))) & 0xffffffffffffffff
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xffffffffffffffff   # splitmix64 finaliser
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xffffffffffffffff
+    return int((x ^ (x >> 31)) & 0xffffffff)

@@ -74,6 +74,20 @@ __device__ __forceinline__ float tg_tanh(float x) {
     return __builtin_copysignf(r, x);
 }
 
+// Counter-based dropout mask (TgDisWeights.dropout_seed): element idx keeps iff tg_hash32(idx + seed*golden) < keep*2^32.
+// "lowbias32" integer finaliser: 5 ALU ops, no state, any element in any order on any rank.
+__host__ __device__ __forceinline__ uint32_t tg_hash32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352dU;
+    x ^= x >> 15;
+    x *= 0x846ca68bU;
+    x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ bool tg_drop_keep(uint32_t idx, uint32_t seed, uint32_t keep_u32) {
+    return tg_hash32(idx + seed * 0x9E3779B9U) < keep_u32;
+}
+
 __device__ __forceinline__ int tg_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int tg_max(int a, int b) { return a > b ? a : b; }
 

@@ -581,6 +581,8 @@ struct HwArgs {
     float* partial;            // [N, nchunk, kMaxOut]
     float keep, scale;         // keep = 1-p, scale = 1/(1-p); p == 0 -> keep = 2 (always), scale = 1
     int N, nchunk, nseqtile;
+    int drop_gen;              // 1: dropout_u is null and the masks come from the counter-based generator
+    uint32_t drop_seed, keep_u32;
 };
 
 // One thread's share of a 128-row x 32-float operand tile: 4 float4 (rows r0 + 32*i, 16-B chunk c).
@@ -812,6 +814,8 @@ __device__ __forceinline__ void hw_epilogue_rows(const ARGS& a, f32x16 (&acc)[2]
         for (int e = 0; e < 4; ++e) {
             float d = fin ? fv[e] : 0.f;
             if (a.dropout_u) d = (uv[p][e] < a.keep) ? d * a.scale : 0.f;
+            else if (a.drop_gen)
+                d = tg_drop_keep((uint32_t)seq * (uint32_t)F + (uint32_t)(fb + e), a.drop_seed, a.keep_u32) ? d * a.scale : 0.f;
 #pragma unroll
             for (int o = 0; o < kMaxOut; ++o)
                 if (o < n_out) part[o] = __builtin_fmaf(d, ow[o][e], part[o]);
@@ -984,6 +988,8 @@ __device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][NJ],
                     if (fb + e >= F) continue;
                     float d = fv[e];
                     if (a.dropout_u) d = (uv[e] < a.keep) ? d * a.scale : 0.f;
+                    else if (a.drop_gen)
+                        d = tg_drop_keep((uint32_t)seq * (uint32_t)F + (uint32_t)(fb + e), a.drop_seed, a.keep_u32) ? d * a.scale : 0.f;
 #pragma unroll
                     for (int o = 0; o < kMaxOut; ++o)
                         if (o < n_out) part[jn][o] = __builtin_fmaf(d, a.w.out_w[(size_t)o * F + fb + e], part[jn][o]);
@@ -1395,6 +1401,17 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     ha.w = *w;
     ha.pooled = pooled;
     ha.dropout_u = (dropout_p > 0.f) ? dropout_uniforms : nullptr;
+    ha.drop_gen = (dropout_p > 0.f && !dropout_uniforms) ? 1 : 0;
+    ha.drop_seed = w->dropout_seed;
+    {
+        const double k32 = (1.0 - (double)dropout_p) * 4294967296.0;
+        ha.keep_u32 = k32 >= 4294967295.0 ? 0xffffffffu : (uint32_t)k32;
+    }
+    if (ha.drop_gen && (size_t)N * w->F > 0xffffffffull) {
+        tg_set_error("tg_dis_score: counter-based dropout indexes N*F = %zu elements with 32 bits; score in chunks",
+                     (size_t)N * w->F);
+        return TG_ERR_ARG;
+    }
     ha.feature_out = feature_out;
     ha.partial = partial;
     ha.keep = 1.f - dropout_p;
@@ -1464,6 +1481,8 @@ struct RescoreArgs {
     float* reward_out;      // [R,N]
     int N, R, F, n_out, col;
     float keep, scale;
+    int drop_gen;
+    uint32_t drop_seed, keep_u32;
 };
 
 // One workgroup per sample: the feature row and the output layer's columns stay in registers over the R masks.
@@ -1490,6 +1509,9 @@ __global__ __launch_bounds__(256) void k_dis_rescore(const RescoreArgs a) {
             const int f = tid + 256 * i;
             float d = fv[i];
             if (u) d = (f < a.F && u[f] < a.keep) ? d * a.scale : 0.f;
+            else if (a.drop_gen)
+                d = tg_drop_keep(((uint32_t)r * (uint32_t)a.N + (uint32_t)nidx) * (uint32_t)a.F + (uint32_t)f, a.drop_seed,
+                                 a.keep_u32) ? d * a.scale : 0.f;
 #pragma unroll
             for (int o = 0; o < kMaxOut; ++o) part[o] = __builtin_fmaf(d, ow[o][i], part[o]);
         }
@@ -1535,8 +1557,12 @@ extern "C" int tg_dis_rescore_dropout(const TgDisWeights* w, const float* featur
                      256 * kRescorePer, w->n_out, col);
         return TG_ERR_ARG;
     }
-    if (!(dropout_p >= 0.f && dropout_p < 1.f) || (dropout_p > 0.f && !dropout_uniforms)) {
-        tg_set_error("tg_dis_rescore_dropout: dropout_p=%g needs uniforms and must be in [0,1)", (double)dropout_p);
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) {
+        tg_set_error("tg_dis_rescore_dropout: dropout_p=%g must be in [0,1)", (double)dropout_p);
+        return TG_ERR_ARG;
+    }
+    if (dropout_p > 0.f && !dropout_uniforms && (size_t)R * N * w->F > 0xffffffffull) {
+        tg_set_error("tg_dis_rescore_dropout: counter-based dropout indexes R*N*F elements with 32 bits");
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;
@@ -1549,6 +1575,12 @@ extern "C" int tg_dis_rescore_dropout(const TgDisWeights* w, const float* featur
     a.N = N; a.R = R; a.F = w->F; a.n_out = w->n_out; a.col = col;
     a.keep = 1.f - dropout_p;
     a.scale = 1.f / (1.f - dropout_p);
+    a.drop_gen = (dropout_p > 0.f && !dropout_uniforms) ? 1 : 0;
+    a.drop_seed = w->dropout_seed;
+    {
+        const double k32 = (1.0 - (double)dropout_p) * 4294967296.0;
+        a.keep_u32 = k32 >= 4294967295.0 ? 0xffffffffu : (uint32_t)k32;
+    }
     tg_prof_begin(TG_KERNEL_DIS_FINAL, (hipStream_t)stream);
     hipLaunchKernelGGL(k_dis_rescore, dim3(N), dim3(256), 0, (hipStream_t)stream, a);
     tg_prof_end((hipStream_t)stream);

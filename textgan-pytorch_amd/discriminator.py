@@ -8,10 +8,9 @@ def forward(dis, inp, dropout_uniforms=None):
     """CNNDiscriminator.forward: logits [N, n_out].  Dropout follows dis.training like nn.Dropout."""
     p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
     with torch.no_grad():
-        du = dropout_uniforms
-        if p > 0 and du is None:
-            du = torch.rand(inp.shape[0], dis.feature_dim, dtype=torch.float32, device=inp.device)
-        return ops.dis_score(dis, inp, dropout_p=p, dropout_uniforms=du, want_reward=False, want_logits=True)["logits"]
+        # without explicit uniforms the masks come from the kernel's counter-based generator (a fresh seed per call)
+        return ops.dis_score(dis, inp, dropout_p=p, dropout_uniforms=dropout_uniforms, want_reward=False,
+                             want_logits=True)["logits"]
 
 
 def get_feature(dis, inp):

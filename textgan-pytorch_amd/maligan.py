@@ -12,7 +12,8 @@ def get_mali_reward(dis, samples, rollout_num, dropout_uniforms=None, generator=
     """MaliGANInstructor.get_mali_reward(samples) with ``self.dis = dis``, ``cfg.rollout_num = rollout_num``.
 
     samples [B,L] int64 on the GPU; returns [B,L] fp32 (every column equal, like the reference's expand).
-    dropout_uniforms: optional [R,B,F] U[0,1) (mask r keeps u < 1-p); drawn with torch.rand when omitted.
+    dropout_uniforms: optional [R,B,F] U[0,1) (mask r keeps u < 1-p); without them the masks are drawn with
+    torch.rand if a ``generator`` is given, else by the kernel's counter-based generator.
     Dropout follows ``dis.training`` as nn.Dropout does (the reference never calls dis.eval())."""
     if not samples.is_cuda:
         raise RuntimeError("textgan_hip get_mali_reward: samples must be on the GPU (got %s); there is no CPU path"
@@ -24,8 +25,9 @@ def get_mali_reward(dis, samples, rollout_num, dropout_uniforms=None, generator=
         feat = ops.dis_score(dis, samples, want_reward=False, want_feature=True, weights=weights)["feature"]
         p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
         du = dropout_uniforms
-        if p > 0 and du is None:
+        if p > 0 and du is None and generator is not None:
             du = torch.rand(R, B, weights[0].F, dtype=torch.float32, device=samples.device, generator=generator)
+        # neither uniforms nor a torch.Generator: counter-based masks inside the kernel (a fresh seed per call)
         probs = ops.dis_rescore_dropout(dis, feat, R, col=1, dropout_p=p, dropout_uniforms=du, weights=weights)
         rewards = torch.mean(probs, dim=0)                 # maligan_instructor.py:149
         rewards = torch.div(rewards, 1 - rewards)          # :150

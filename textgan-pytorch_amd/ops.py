@@ -75,8 +75,20 @@ def gen_sample(gen, N, L, start_letter, uniforms, forced=None, precision=None):
     return out
 
 
+def _dropout_args(w, N, dropout_p, dropout_uniforms, dropout_seed, count):
+    """Explicit uniforms (parity / reproducibility) or, without them, a seed for the in-kernel counter-based masks."""
+    if dropout_p > 0.0 and dropout_uniforms is not None:
+        if dropout_uniforms.numel() != count:
+            raise RuntimeError("textgan_hip: dropout_uniforms must have %d elements, got %d"
+                               % (count, dropout_uniforms.numel()))
+        return _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms")
+    if dropout_p > 0.0:
+        w.dropout_seed = _lib.next_dropout_seed() if dropout_seed is None else int(dropout_seed) & 0xffffffff
+    return None
+
+
 def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_reward=True, want_logits=False,
-              want_feature=False, reward_out=None, weights=None, precision=None):
+              want_feature=False, reward_out=None, weights=None, precision=None, dropout_seed=None):
     """tg_dis_score: CNNDiscriminator.forward (models/discriminator.py:40-64) + softmax column
     (utils/rollout.py:146-148).  seqs [N,L]; returns dict(reward [N], logits [N,n_out], feature [N,F])."""
     w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
@@ -86,19 +98,18 @@ def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_rewar
     reward = reward_out if reward_out is not None else (torch.empty(N, dtype=F32, device=dev) if want_reward else None)
     logits = torch.empty(N, w.n_out, dtype=F32, device=dev) if want_logits else None
     feat = torch.empty(N, w.F, dtype=F32, device=dev) if want_feature else None
-    if dropout_p > 0.0 and dropout_uniforms is not None and dropout_uniforms.numel() != N * w.F:
-        raise RuntimeError("textgan_hip: dropout_uniforms must have N*F = %d elements" % (N * w.F))
+    du = _dropout_args(w, N, dropout_p, dropout_uniforms, dropout_seed, N * w.F)
     nbytes = _lib.lib().tg_dis_workspace_bytes(C.byref(w), N, L)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().tg_dis_score(
         C.byref(w), _lib.dev_ptr(s, I64, "seqs"), N, L, int(col), float(dropout_p),
-        _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms"), _lib.dev_ptr(reward), _lib.dev_ptr(logits),
+        du, _lib.dev_ptr(reward), _lib.dev_ptr(logits),
         _lib.dev_ptr(feat), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
     return {"reward": reward, "logits": logits, "feature": feat}
 
 
 def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout_uniforms=None, reward_out=None,
-                      weights=None, precision=None):
+                      weights=None, precision=None, dropout_seed=None):
     """tg_dis_score_rollout: the scorer over tg_gen_rollout's [R,L,B,L] completions with prefix reuse
     (windows inside the tokens a completion shares with its sentence are evaluated once per sentence).
     Returns raw reward rows [R*L, B]."""
@@ -110,13 +121,12 @@ def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout
         raise RuntimeError("textgan_hip: completions must be [R,L,B,L] matching sentences [B,L]")
     dev = s.device
     reward = reward_out if reward_out is not None else torch.empty(R * L, B, dtype=F32, device=dev)
-    if dropout_p > 0.0 and dropout_uniforms is not None and dropout_uniforms.numel() != R * L * B * w.F:
-        raise RuntimeError("textgan_hip: dropout_uniforms must have R*L*B*F elements")
+    du = _dropout_args(w, R * L * B, dropout_p, dropout_uniforms, dropout_seed, R * L * B * w.F)
     nbytes = _lib.lib().tg_dis_score_rollout_workspace_bytes(C.byref(w), B, L, R)
     ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
     _lib.check(_lib.lib().tg_dis_score_rollout(
         C.byref(w), _lib.dev_ptr(s, I64, "sentences"), _lib.dev_ptr(comp, I64, "completions"), B, L, R, int(col),
-        float(dropout_p), _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms"), _lib.dev_ptr(reward, F32, "reward"),
+        float(dropout_p), du, _lib.dev_ptr(reward, F32, "reward"),
         _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
     return reward
 
@@ -131,7 +141,8 @@ def reward_reduce(raw, B, L, R):
     return out
 
 
-def dis_rescore_dropout(dis, feature, R, col=1, dropout_p=0.0, dropout_uniforms=None, weights=None):
+def dis_rescore_dropout(dis, feature, R, col=1, dropout_p=0.0, dropout_uniforms=None, weights=None,
+                        dropout_seed=None):
     """tg_dis_rescore_dropout: R dropout masks + output layer + softmax column over precomputed highway features
     (the loop of MaliGANInstructor.get_mali_reward, instructor/real_data/maligan_instructor.py:142-147).
     feature [N,F]; dropout_uniforms [R,N,F]; returns [R,N]."""
@@ -139,11 +150,9 @@ def dis_rescore_dropout(dis, feature, R, col=1, dropout_p=0.0, dropout_uniforms=
     N = feature.shape[0]
     if feature.dim() != 2 or feature.shape[1] != w.F:
         raise RuntimeError("textgan_hip: feature must be [N, %d]" % w.F)
-    if dropout_p > 0.0 and (dropout_uniforms is None or dropout_uniforms.numel() != R * N * w.F):
-        raise RuntimeError("textgan_hip: dropout_uniforms must have R*N*F = %d elements" % (R * N * w.F))
+    du = _dropout_args(w, R * N, dropout_p, dropout_uniforms, dropout_seed, R * N * w.F)
     out = torch.empty(R, N, dtype=F32, device=feature.device)
     _lib.check(_lib.lib().tg_dis_rescore_dropout(
-        C.byref(w), _lib.dev_ptr(feature, F32, "feature"), N, R, col, float(dropout_p),
-        _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms") if dropout_p > 0.0 else None,
+        C.byref(w), _lib.dev_ptr(feature, F32, "feature"), N, R, col, float(dropout_p), du,
         _lib.dev_ptr(out), _lib.stream_ptr()))
     return out

@@ -21,6 +21,9 @@ class ROLLOUT:
     dis_precision = None
     #: arithmetic of the generator's vocabulary projection: None = library default, "fp32" or "split_f16" (TG_GEN_*)
     gen_precision = None
+    #: dropout masks of the scorer when no dropout_uniforms are passed: "kernel" = counter-based, generated inside the
+    #: highway epilogue from a per-call seed (no [N, F] tensor); "torch" = torch.rand uniforms (ROLLOUT.generator)
+    dropout_rng = "kernel"
 
     def __init__(self, gen, gpu=True):
         self.gen = gen
@@ -103,13 +106,16 @@ class ROLLOUT:
                 with self._timed("dis_score"):
                     for lo in range(0, Rl, step):
                         hi = min(Rl, lo + step)
-                        du = None
-                        if p > 0:
-                            du = (du_all[lo * L * B:hi * L * B].contiguous() if du_all is not None
-                                  else self._rand(((hi - lo) * L * B, F), dev))
+                        du, seed = None, None
+                        if p > 0 and du_all is not None:
+                            du = du_all[lo * L * B:hi * L * B].contiguous()
+                        elif p > 0 and self.dropout_rng == "torch":
+                            du = self._rand(((hi - lo) * L * B, F), dev)
+                        elif p > 0:
+                            seed = _lib.next_dropout_seed(plan.rank)
                         ops.dis_score_rollout(dis, sentences, comp[lo:hi], col=current_k + 1, dropout_p=p,
                                               dropout_uniforms=du, reward_out=raw_local[lo * L:hi * L],
-                                              weights=weights)
+                                              weights=weights, dropout_seed=seed)
             with self._timed("exchange"):
                 raw = tdist.gather_rows(raw_local, plan, L, self.group)
             with self._timed("reduce"):
