@@ -654,7 +654,11 @@ void k_gen(const GenArgs a) {
                 if (q < ng_valid) {
                     const float2 r = rq[q];
                     if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
-                    s += (double)r.y * fac;
+                    const double c = (double)r.y * fac;
+                    s += c;
+                    // the record is only read again by the group search below, which wants this product: leave it in
+                    // place of the (max, sum) pair (same 8 bytes, same owner thread)
+                    reinterpret_cast<double*>(rec)[(q * kNSpan + sp) * kRows + n] = c;
                 }
             }
             sbuf[sp * kRows + n] = s;
@@ -675,20 +679,16 @@ void k_gen(const GenArgs a) {
             }
             if (sel == sp) {  // exactly one of the row's 8 threads owns the draw
                 int gq = ng_valid - 1;
-                double fac = 1.0;
-                float fx = M;
-                float2 rq[16];
+                double cq[16];  // the groups' contributions at the row's scale, left by the span-sum pass
 #pragma unroll
-                for (int q = 0; q < 16; ++q) rq[q] = rec[(tg_min(q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
+                for (int q = 0; q < 16; ++q)
+                    cq[q] = reinterpret_cast<const double*>(rec)[(tg_min(q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
                 bool found = false;
 #pragma unroll
                 for (int q = 0; q < 16; ++q) {
                     if (q < ng_valid && !found) {
-                        const float2 r = rq[q];
-                        if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
-                        const double c = (double)r.y * fac;
-                        if (p + c > target || q == ng_valid - 1) { gq = q; found = true; }
-                        else p += c;
+                        if (p + cq[q] > target || q == ng_valid - 1) { gq = q; found = true; }
+                        else p += cq[q];
                     }
                 }
                 selv[n] = sp_lo + gq * EG;
