@@ -166,7 +166,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(ctr, 1);
-        item = __builtin_amdgcn_readfirstlane(item);
+        // gridDim.y > 1 (few sequences: the sentence pass): the items are dealt round-robin to the y workgroups
+        item = __builtin_amdgcn_readfirstlane(item) * (int)gridDim.y + (int)blockIdx.y;
         if (item >= a.n_items) break;
         const int k = a.items[item].k, mt = a.items[item].mt;
         const bool merged = SPLIT && k == 0xFF;  // mt = merged tile index
@@ -1205,7 +1206,10 @@ int launch_conv_t(const ConvArgs& ca, size_t sm, hipStream_t stream) {
         conv_set = sm;
     }
     tg_prof_begin(MODE == kConvStoreAll ? TG_KERNEL_DIS_PREFIX : TG_KERNEL_DIS_CONV, stream);
-    hipLaunchKernelGGL((k_dis_conv<MODE, SPLIT>), dim3((ca.N + ca.S - 1) / ca.S), dim3(kConvThreads), sm, stream, ca);
+    // a grid of fewer workgroups than CUs (the sentence pass: B sequences) is widened over the (width, tile) items
+    const int gx = (ca.N + ca.S - 1) / ca.S;
+    const int gy = (MODE == kConvStoreAll && gx < 256) ? tg_min_host(tg_min_host(8, ca.n_items), (512 + gx - 1) / gx) : 1;
+    hipLaunchKernelGGL((k_dis_conv<MODE, SPLIT>), dim3(gx, gy), dim3(kConvThreads), sm, stream, ca);
     tg_prof_end(stream);
     return TG_OK;
 }
