@@ -88,6 +88,28 @@ __host__ __device__ __forceinline__ bool tg_drop_keep(uint32_t idx, uint32_t see
     return tg_hash32(idx + seed * 0x9E3779B9U) < keep_u32;
 }
 
+// Phase-cycle diagnostics (tools/ubench/stamps.py, conv_stamps.py) exist only in a `make DIAG=1` build: the
+// shipped library reads no clock and takes no pointer from the environment.
+#ifndef TG_DIAG
+#define TG_DIAG 0
+#endif
+__device__ __forceinline__ long long tg_clock() {
+#if TG_DIAG
+    return clock64();
+#else
+    return 0;
+#endif
+}
+inline long long* tg_diag_pointer(const char* env_name) {
+#if TG_DIAG
+    const char* d = getenv(env_name);
+    return d ? (long long*)strtoull(d, nullptr, 0) : nullptr;
+#else
+    (void)env_name;
+    return nullptr;
+#endif
+}
+
 __device__ __forceinline__ int tg_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int tg_max(int a, int b) { return a > b ? a : b; }
 

@@ -72,6 +72,7 @@ struct ConvArgs {
     uint8_t mfmax[kMaxMerged], mfmin[kMaxMerged];
     const MergedMeta* mmeta;   // [n_merged]
     ConvItem items[kMaxItems]; // sorted by cost, heaviest first
+    long long* stamps;         // diagnostic (TG_CONV_STAMPS env = device pointer): per workgroup [16] clock64 values
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -86,6 +87,7 @@ constexpr int kERowH = 2 * kERow;  // LDS halves per embedded token in the split
 //                fp32-MFMA cycles.
 template <int MODE, bool SPLIT>
 __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
+    const long long st0 = tg_clock();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* ebuf = reinterpret_cast<float*>(smem);  // [L][S][68] floats, or [L][S][136] halves (same bytes)
     _Float16* ebuf_h = reinterpret_cast<_Float16*>(smem);
@@ -163,12 +165,16 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     }
 
     float pmax = 0.f;  // largest pooled value this lane stored
+    const long long st1 = tg_clock();
+    long long st_mfma = 0;
+    int st_items = 0;
     for (;;) {
         int item = 0;
         if (lane == 0) item = atomicAdd(ctr, 1);
         // gridDim.y > 1 (few sequences: the sentence pass): the items are dealt round-robin to the y workgroups
         item = __builtin_amdgcn_readfirstlane(item) * (int)gridDim.y + (int)blockIdx.y;
         if (item >= a.n_items) break;
+        const long long st_item = tg_clock();
         const int k = a.items[item].k, mt = a.items[item].mt;
         const bool merged = SPLIT && k == 0xFF;  // mt = merged tile index
         const int f = merged ? a.mfmax[mt] : a.w.f[k];
@@ -329,6 +335,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 finish_chunk(nb0, nbc);
             }
         }
+        if (a.stamps) { st_mfma += tg_clock() - st_item; ++st_items; }
         if (MODE == kConvStoreAll) continue;
         // combine the TT time sub-positions of a sequence (lanes n, n+S, n+2S, ...)
         for (int off = S; off < 32; off <<= 1) {
@@ -385,6 +392,11 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 }
             }
         }
+    }
+    if (a.stamps && lane == 0) {
+        const long long st2 = tg_clock();
+        long long* o = a.stamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 4;
+        o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st_mfma; o[3] = st_items;
     }
     if (MODE != kConvStoreAll && a.pooled_absmax) {  // one atomic per workgroup
 #pragma unroll
@@ -1142,6 +1154,7 @@ MergePlan plan_merge(const TgDisWeights* w) {
 int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem) {
     ca.w = *w;
     ca.L = L;
+    ca.stamps = tg_diag_pointer("TG_CONV_STAMPS");
     const MergePlan pl = plan_merge(w);
     const int LP = L + pl.pad_rows;  // LDS rows per sequence
     int S = 32, log2S = 5;

@@ -249,7 +249,7 @@ void k_gen(const GenArgs a) {
 
     long long st_cell = 0, st_proj = 0, st_draw = 0, st_n = 0, st_d[4] = {0, 0, 0, 0};
     for (int t = t0; t < L; ++t) {
-        const long long c0 = clock64();
+        const long long c0 = tg_clock();
         // ============================================================== LSTM cell
         if constexpr (REG) {
             float xb[16];
@@ -361,7 +361,7 @@ void k_gen(const GenArgs a) {
             continue;
         }
 
-        const long long c1 = clock64();
+        const long long c1 = tg_clock();
         // ============================================================== projection + online softmax
         // The pipelined path works in base 2: h (B operand) and the bias are pre-multiplied by log2(e), so the
         // MFMA delivers l' = l*log2(e) and a weight is one v_exp_f32 (1 ulp) of (l' - m'): 2 VALU per entry
@@ -480,7 +480,10 @@ void k_gen(const GenArgs a) {
                             const f32x4* p = reinterpret_cast<const f32x4*>(a.w.w_out + (size_t)tg_min(v, V - 1) * kH + 16 * hh);
 #pragma unroll
                             for (int i = 0; i < 4; ++i) dst.w[i] = p[i];
-                            dst.bias[0] = hh ? 0.f : (v < V ? a.w.b_out[v] * kL2E : TG_NEG_BIG);
+                            // every lane loads (the k = 1 lanes meet b = 0 in the MFMA, any finite value does): a
+                            // select on hh turns into a divergent branch with a full vmcnt(0) wait in the pipelined block
+                            const float bv = a.w.b_out[tg_min(v, V - 1)] * kL2E;
+                            dst.bias[0] = v < V ? bv : TG_NEG_BIG;
                         }
                     };
                     auto mfma_tile = [&](int q, const AFrag& af) {
@@ -555,9 +558,9 @@ void k_gen(const GenArgs a) {
                         // invariant at loop head: acc0 = tile q (q even), s1 = tile q+1, s0 = tile q+2 in flight
                         for (; q + 2 < nfull; q += 2) {
                             acc1 = mfma_tile(q + 1, s1); softmax_tile(acc0, q); interleave();
-                            if (q + 3 < nfull) load_a(q + 3, s1);
+                            load_a(tg_min(q + 3, nfull - 1), s1);
                             acc0 = mfma_tile(q + 2, s0); softmax_tile(acc1, q + 1); interleave();
-                            if (q + 4 < nfull) load_a(q + 4, s0);
+                            load_a(tg_min(q + 4, nfull - 1), s0);
                         }
                         softmax_tile(acc0, q);
                         if (q + 1 < nfull) { acc1 = mfma_tile(q + 1, s1); softmax_tile(acc1, q + 1); }
@@ -570,15 +573,18 @@ void k_gen(const GenArgs a) {
                         if (nfull > 2) load_a(2, a2);
                         acc0 = mfma_tile(0, a0);
                         int q = 0;
-                        // invariant at loop head: acc0 = tile q (q % 6 == 0), a1 = tile q+1, a2 = tile q+2 in flight
+                        // invariant at loop head: acc0 = tile q (q % 6 == 0), a1 = tile q+1, a2 = tile q+2 in flight.
+                        // Loads past the last tile are clamped, not skipped: a branch would cut the body into several
+                        // basic blocks, the interleave below works within one, and without a store to pin it (teacher-
+                        // forced mode) the softmax work sinks into the last block with six accumulators live.
                         for (; q + 6 < nfull; q += 6) {
                             load_a(q + 3, a0); acc1 = mfma_tile(q + 1, a1); softmax_tile(acc0, q);     interleave();
                             load_a(q + 4, a1); acc0 = mfma_tile(q + 2, a2); softmax_tile(acc1, q + 1); interleave();
                             load_a(q + 5, a2); acc1 = mfma_tile(q + 3, a0); softmax_tile(acc0, q + 2); interleave();
                             load_a(q + 6, a0); acc0 = mfma_tile(q + 4, a1); softmax_tile(acc1, q + 3); interleave();
-                            if (q + 7 < nfull) load_a(q + 7, a1);
+                            load_a(tg_min(q + 7, nfull - 1), a1);
                             acc1 = mfma_tile(q + 5, a2); softmax_tile(acc0, q + 4); interleave();
-                            if (q + 8 < nfull) load_a(q + 8, a2);
+                            load_a(tg_min(q + 8, nfull - 1), a2);
                             acc0 = mfma_tile(q + 6, a0); softmax_tile(acc1, q + 5); interleave();
                         }
                         // tail (at most 6 tiles): acc0 = tile q; a1 = tile q+1, a2 = tile q+2 if they exist
@@ -603,10 +609,10 @@ void k_gen(const GenArgs a) {
                 for (int q = 0; q < NT; ++q) tile_any(q, dummy);
             }
         }
-        const long long c2 = clock64();
+        const long long c2 = tg_clock();
         mbuf[sp * kRows + n] = m_run;
         __syncthreads();
-        const long long d0 = clock64();
+        const long long d0 = tg_clock();
         float M = mbuf[n];
 #pragma unroll
         for (int s = 1; s < kNSpan; ++s) M = __builtin_fmaxf(M, mbuf[s * kRows + n]);
@@ -664,7 +670,7 @@ void k_gen(const GenArgs a) {
             sbuf[sp * kRows + n] = s;
         }
         __syncthreads();
-        const long long d1 = clock64();
+        const long long d1 = tg_clock();
         {
             double S = 0.0;
 #pragma unroll
@@ -698,7 +704,7 @@ void k_gen(const GenArgs a) {
             }
         }
         __syncthreads();  // selections visible; every read of rec is done (wbuf / xbuf alias-free from here)
-        const long long d2 = clock64();
+        const long long d2 = tg_clock();
         // cooperative recompute of the chosen groups: 8 threads per row, each EG/8 entries of that row with the
         // row's h held in registers (REG) or read from LDS per chunk
         if constexpr (SPLIT) {
@@ -777,7 +783,7 @@ void k_gen(const GenArgs a) {
             }
         }
         __syncthreads();
-        const long long d3 = clock64();
+        const long long d3 = tg_clock();
         if (tid < kRows) {
             const int gv = selv[n];
             const int vend = tg_min(V, (gv / Ls + 1) * Ls);
@@ -816,7 +822,7 @@ void k_gen(const GenArgs a) {
         }
         __syncthreads();
         tok = tokbuf[n];
-        const long long c3 = clock64();
+        const long long c3 = tg_clock();
         st_cell += c1 - c0; st_proj += c2 - c1; st_draw += c3 - c2; st_n += 1;
         st_d[0] += d0 - c2; st_d[1] += d1 - d0; st_d[2] += d2 - d1; st_d[3] += d3 - d2;
     }
@@ -1096,7 +1102,7 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
     a.forced = forced;
     a.out = completions;
     a.rollout = 1;
-    { const char* d = getenv("TG_STAMPS"); a.stamps = d ? (long long*)strtoull(d, nullptr, 0) : nullptr; }
+    a.stamps = tg_diag_pointer("TG_STAMPS");
     a.B = B;
     a.L = L;
     a.R = R;
