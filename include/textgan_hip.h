@@ -225,6 +225,38 @@ int tg_dis_rescore_dropout(const TgDisWeights* w, const float* feature, int N,
                            void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Backward of the policy-gradient loss.
+ * Replaces what autograd does behind SeqGAN_G.batchPGLoss (models/SeqGAN_G.py:21-39), MaliGAN_G.adv_loss
+ * (models/MaliGAN_G.py:21-39) and SentiGAN_G.batchPGLoss (models/SentiGAN_G.py:47-65): those build the
+ * [B*L, V] log-softmax matrix, multiply it with a [B, L, V] one-hot of the target and back-propagate through both.
+ * The forward half is tg_gen_teacher_forced (logp_out, lse_out, states_out); this call takes
+ *   coeff  [N,L]  dLoss/dlogp[n,t]   (SeqGAN / MaliGAN: -reward[n,t] * grad_out;
+ *                                     SentiGAN, which sums probabilities: -(1-reward[n,t]) * exp(logp[n,t]) * grad_out)
+ *   lse    [N,L], states [L+1,N,2,H]  as written by tg_gen_teacher_forced for the same (w, inp)
+ * and writes the gradients of all seven parameters (each buffer fully overwritten; shapes as in TgGenWeights;
+ * b_ih and b_hh receive the same values).  Row padding_idx of the embedding gradient stays zero, as
+ * nn.Embedding(padding_idx=...) has it (models/generator.py:33); pass -1 for none.
+ * The logits are recomputed tile by tile on the matrix cores; no [N*L, V] buffer exists.  fp32 throughout.
+ * The embedding gradient is accumulated with float atomics (the order of additions, and so the last bit, can
+ * vary between calls -- as torch's own embedding backward on a GPU); everything else is summed in fixed order.
+ * Supported: E = H = 32 (every SeqGAN / MaliGAN / SentiGAN configuration of the reference); TG_ERR_ARG otherwise. */
+typedef struct TgGenGrads {
+    float* emb;    /* [V, E]   */
+    float* w_ih;   /* [4H, E]  */
+    float* w_hh;   /* [4H, H]  */
+    float* b_ih;   /* [4H]     */
+    float* b_hh;   /* [4H]     */
+    float* w_out;  /* [V, H]   */
+    float* b_out;  /* [V]      */
+} TgGenGrads;
+size_t tg_gen_pg_backward_workspace_bytes(const TgGenWeights* w, int N, int L);
+int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
+                       const int64_t* target, const float* coeff,
+                       const float* lse, const float* states, int N, int L,
+                       int64_t padding_idx, const TgGenGrads* grads,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Reward reshape + mean.
  * Replaces torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153):
  * a reinterpretation of the flat [R*L, B] buffer, not a permute:
@@ -244,6 +276,7 @@ int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
 #define TG_KERNEL_DIS_FINAL 4     /* k_dis_final                                  */
 #define TG_KERNEL_REDUCE 5        /* k_reward_reduce                              */
 #define TG_KERNEL_DIS_PREFIX 6    /* k_dis_conv<store-all> + k_dis_prefix_scan    */
+#define TG_KERNEL_PG_BACKWARD 7   /* k_pg_prep .. k_pg_reduce (one bracket)       */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

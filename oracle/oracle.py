@@ -217,3 +217,58 @@ def mali_reward(dis, samples, R, dropout_p=0.0, dropout_uniforms=None):
     rew = (rew / np.sum(rew, dtype=np.float32)).astype(np.float32)
     rew = (rew - np.mean(rew, dtype=np.float32)).astype(np.float32)
     return np.broadcast_to(rew[:, None], (B, L)).copy()
+
+
+def pg_loss_grads(gen, inp, target, weight, use_prob=False, padding_idx=0):
+    """Policy-gradient loss and its parameter gradients, restated by hand in numpy (float64 arithmetic on the fp32
+    parameters): SeqGAN_G.batchPGLoss models/SeqGAN_G.py:21-39 (use_prob False, weight = reward),
+    MaliGAN_G.adv_loss models/MaliGAN_G.py:21-39 (same), SentiGAN_G.batchPGLoss models/SentiGAN_G.py:47-65
+    (use_prob True, weight = 1 - reward).  loss = -sum(pred * weight), pred = log-softmax (or softmax) of
+    lstm2out(lstm(emb(inp))) picked at the target; the gradients are what autograd returns for the seven
+    parameters of LSTMGenerator (models/generator.py:33-35), the embedding's padding_idx row left at zero.
+    Returns (loss, dict of gradients keyed like the state_dict)."""
+    emb, w_ih, w_hh, b_ih, b_hh, w_out, b_out = [x.astype(np.float64) for x in gen.a]
+    inp, target = _i64(inp), _i64(target)
+    N, L = inp.shape
+    H, V = gen.H, gen.V
+    weight = np.broadcast_to(np.asarray(weight, np.float64), (N, L))
+    sig = lambda z: 1.0 / (1.0 + np.exp(-z))
+    h = np.zeros((N, H)); c = np.zeros((N, H))
+    hs, cs, gates = [h], [c], []
+    for t in range(L):  # nn.LSTM, gate order i,f,g,o (models/generator.py:51)
+        z = emb[inp[:, t]] @ w_ih.T + h @ w_hh.T + b_ih + b_hh
+        i, f, g, o = sig(z[:, :H]), sig(z[:, H:2 * H]), np.tanh(z[:, 2 * H:3 * H]), sig(z[:, 3 * H:])
+        c = f * c + i * g
+        h = o * np.tanh(c)
+        hs.append(h); cs.append(c); gates.append((i, f, g, o))
+    hall = np.stack(hs[1:], 1)                                  # [N,L,H]
+    logits = hall @ w_out.T + b_out                             # lstm2out (models/generator.py:53)
+    m = logits.max(-1, keepdims=True)
+    logsm = logits - m - np.log(np.exp(logits - m).sum(-1, keepdims=True))
+    logp = np.take_along_axis(logsm, target[..., None], -1)[..., 0]
+    pred = np.exp(logp) if use_prob else logp
+    loss = -(pred * weight).sum()
+    coeff = -weight * (np.exp(logp) if use_prob else 1.0)       # dLoss/dlogp
+    dlogits = -np.exp(logsm) * coeff[..., None]
+    np.add.at(dlogits, (np.arange(N)[:, None], np.arange(L)[None, :], target), coeff)
+    d = {"lstm2out.weight": np.einsum("ntv,nth->vh", dlogits, hall), "lstm2out.bias": dlogits.sum((0, 1))}
+    dh_proj = dlogits @ w_out                                   # [N,L,H]
+    d_emb = np.zeros_like(emb); d_wih = np.zeros_like(w_ih); d_whh = np.zeros_like(w_hh); d_b = np.zeros(4 * H)
+    dh_next = np.zeros((N, H)); dc_next = np.zeros((N, H))
+    for t in range(L - 1, -1, -1):
+        i, f, g, o = gates[t]
+        tc = np.tanh(cs[t + 1])
+        dh = dh_proj[:, t] + dh_next
+        dc = dc_next + dh * o * (1 - tc * tc)
+        da = np.concatenate([dc * g * i * (1 - i), dc * cs[t] * f * (1 - f), dc * i * (1 - g * g),
+                             dh * tc * o * (1 - o)], 1)         # [N,4H] pre-activation gradients
+        x = emb[inp[:, t]]
+        d_wih += da.T @ x; d_whh += da.T @ hs[t]; d_b += da.sum(0)
+        np.add.at(d_emb, inp[:, t], da @ w_ih)
+        dh_next = da @ w_hh
+        dc_next = dc * f
+    if padding_idx is not None and 0 <= padding_idx < V:
+        d_emb[padding_idx] = 0.0
+    d.update({"embeddings.weight": d_emb, "lstm.weight_ih_l0": d_wih, "lstm.weight_hh_l0": d_whh,
+              "lstm.bias_ih_l0": d_b, "lstm.bias_hh_l0": d_b.copy()})
+    return float(loss), {k: v.astype(np.float32) for k, v in d.items()}

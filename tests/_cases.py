@@ -78,3 +78,27 @@ def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, t
         # every boundary between the two tokens must sit within tie_tol of u
         assert np.all(np.abs(cdf[lo:hi] - u) <= tie_tol), (i, gi + 1, b, t, a, c, u, cdf[lo:hi])
     return agree
+
+
+PG_KEYS = ("embeddings.weight", "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bias_ih_l0", "lstm.bias_hh_l0",
+           "lstm2out.weight", "lstm2out.bias")
+
+
+def pg_inputs(c):
+    """(gen state_dict, inp, target, reward, use_prob, weight) of a pg_loss golden (tools/make_goldens_pg.py)."""
+    V, L, B = int(c["V"]), int(c["L"]), int(c["B"])
+    sd = synth.gen_state(V, 32, 32, seed=int(c["gseed"]), std=float(c["gstd"]))
+    target = synth.tokens(int(c["sseed"]), (B, L), V)
+    inp = np.concatenate([np.full((B, 1), int(c["start_letter"]), np.int64), target[:, :-1]], 1)
+    reward = synth.uniform01(int(c["rseed"]), (B, L)).astype(np.float32)
+    senti = str(c["model"]) == "sentigan"
+    return sd, inp, target, reward, senti, (1.0 - reward if senti else reward)
+
+
+def assert_grads_close(got, want, rel=2e-5, what=""):
+    """Per tensor: max |got - want| <= rel * max |want| (gradients of one tensor share a scale)."""
+    for k in PG_KEYS:
+        g, w = np.asarray(got[k], np.float64), np.asarray(want[k], np.float64)
+        assert g.shape == w.shape, (k, g.shape, w.shape)
+        err, scale = np.abs(g - w).max(), np.abs(w).max()
+        assert err <= rel * scale + 1e-9, "%s %s: max err %.3e vs scale %.3e" % (what, k, err, scale)

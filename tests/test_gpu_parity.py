@@ -425,3 +425,65 @@ def test_errors_and_cpu_inputs():
     bad = tg.modules.LSTMGenerator(48, 96, 100, 20).to(DEV)  # H not in {32,64,128,256,512}
     with pytest.raises(RuntimeError):
         tg.ops.gen_sample(bad, 4, 20, 1, torch.rand(20, 4, device=DEV))
+
+
+# ------------------------------------------------------------------ policy-gradient loss
+def _pg_gen(c, sd):
+    g = tg.modules.LSTMGenerator(32, 32, int(c["V"]), int(c["L"]), padding_idx=int(c["padding_idx"]),
+                                 name=str(c["model"]))
+    return tg.modules.load_numpy_state(g, sd, DEV)
+
+
+def _grads_of(gen):
+    return {k: p.grad.detach().cpu().numpy() for k, p in gen.named_parameters()}
+
+
+@pytest.mark.parametrize("name", _cases.names("pg_loss"))
+def test_pg_loss_and_gradients(name):
+    """pgloss.batchPGLoss / adv_loss + .backward() against the reference's loss and .grad (golden) and the oracle."""
+    c = _cases.load(name)
+    sd, inp, target, reward, senti, weight = _cases.pg_inputs(c)
+    gen = _pg_gen(c, sd)
+    fn = tg.pgloss.adv_loss if str(c["model"]) == "maligan" else tg.pgloss.batchPGLoss
+    loss = fn(gen, _t(inp), _t(target), _t(reward))
+    gen.zero_grad()
+    loss.backward()
+    assert loss.item() == pytest.approx(float(c["loss"]), rel=1e-5)
+    got = _grads_of(gen)
+    _cases.assert_grads_close(got, {k: c["grad." + k] for k in _cases.PG_KEYS}, rel=5e-5, what=name + " vs reference")
+    oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, weight, use_prob=senti,
+                                         padding_idx=int(c["padding_idx"]))
+    assert loss.item() == pytest.approx(oloss, rel=1e-5)
+    _cases.assert_grads_close(got, ograds, rel=5e-5, what=name + " vs oracle")
+    assert not got["embeddings.weight"][int(c["padding_idx"])].any()
+
+
+def test_pg_loss_c2_shape_against_oracle():
+    """Adversarial-step shape of the real-data config (V5255 L51 B64): gradients against the oracle, an optimizer
+    step through the returned autograd node, ragged row / vocabulary tails (64*51 and 5255 are not multiples of 32)."""
+    V, L, B = 5255, 51, 64
+    sd = synth.gen_state(V, 32, 32, seed=0, std=0.1)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L, name="seqgan"), sd, DEV)
+    target = synth.tokens(31, (B, L), V)
+    inp = np.concatenate([np.ones((B, 1), np.int64), target[:, :-1]], 1)
+    reward = synth.uniform01(32, (B, L)).astype(np.float32)
+    opt = torch.optim.Adam(gen.parameters(), lr=1e-2)
+    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+    opt.zero_grad()
+    loss.backward()
+    oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, reward, padding_idx=0)
+    assert loss.item() == pytest.approx(oloss, rel=1e-5)
+    _cases.assert_grads_close(_grads_of(gen), ograds, rel=5e-5, what="c2")
+    before = gen.lstm2out.weight.detach().clone()
+    opt.step()
+    assert (gen.lstm2out.weight.detach() - before).abs().max().item() > 1e-3
+    loss2 = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+    assert loss2.item() < loss.item()  # one Adam step on the same batch lowers the loss
+
+
+def test_pg_backward_rejects_other_shapes():
+    gen = tg.modules.synthetic_generator(100, 32, 64, 20, device=DEV)
+    t = _t(synth.tokens(1, (4, 20), 100))
+    loss = tg.pgloss.batchPGLoss(gen, t, t, torch.ones(4, 20, device=DEV))
+    with pytest.raises(RuntimeError, match="E = H = 32"):
+        loss.backward()

@@ -114,3 +114,15 @@ def test_mali_reward_matches_reference(name):
     assert rew.shape == (B, L)
     np.testing.assert_allclose(rew, c["reward"], atol=1e-4 / B, rtol=1e-4)
     assert np.array_equal(rew, np.broadcast_to(rew[:, :1], rew.shape))
+
+
+@pytest.mark.parametrize("name", _cases.names("pg_loss"))
+def test_pg_loss_grads_match_reference(name):
+    """oracle.pg_loss_grads (hand-written backward) against loss / .grad of the reference's batchPGLoss / adv_loss."""
+    c = _cases.load(name)
+    sd, inp, target, reward, senti, weight = _cases.pg_inputs(c)
+    loss, grads = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, weight, use_prob=senti,
+                                       padding_idx=int(c["padding_idx"]))
+    assert loss == pytest.approx(float(c["loss"]), rel=2e-6)
+    _cases.assert_grads_close(grads, {k: c["grad." + k] for k in _cases.PG_KEYS}, rel=2e-5, what=name)
+    assert not grads["embeddings.weight"][int(c["padding_idx"])].any()

@@ -12,7 +12,7 @@ __all__ = ["synth", "ROLLOUT", "install", "sample", "cal_nll", "modules", "ops",
 
 def __getattr__(name):  # torch-dependent parts load lazily
     import importlib
-    if name in ("modules", "ops", "dist", "rollout", "generator", "nll", "discriminator", "maligan", "_lib"):
+    if name in ("modules", "ops", "dist", "rollout", "generator", "nll", "discriminator", "maligan", "pgloss", "_lib"):
         return importlib.import_module("." + name, __name__)
     if name in ("ROLLOUT", "install"):
         return getattr(importlib.import_module(".rollout", __name__), name)

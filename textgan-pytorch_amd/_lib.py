@@ -17,16 +17,22 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
            "tg_dis_workspace_bytes",
            "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
+           "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
            "tg_reward_reduce",
            "tg_profile_enable", "tg_profile_read"]
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
-           "dis_prefix": 6}
+           "dis_prefix": 6, "pg_backward": 7}
 
 
 class GenW(C.Structure):
     _fields_ = [(k, C.c_void_p) for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")] + \
                [("V", C.c_int32), ("E", C.c_int32), ("H", C.c_int32), ("precision", C.c_int32)]
+
+
+class GenGrads(C.Structure):
+    """TgGenGrads: gradient buffers, same order and shapes as the GenW pointers."""
+    _fields_ = [(k, C.c_void_p) for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
 
 
 class DisW(C.Structure):
@@ -73,6 +79,11 @@ def lib():
                                              C.c_void_p, C.c_void_p]
         l.tg_dis_rescore_dropout.restype = C.c_int
         l.tg_reward_reduce.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+        l.tg_gen_pg_backward_workspace_bytes.restype = C.c_size_t
+        l.tg_gen_pg_backward_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.tg_gen_pg_backward.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
+                                                           C.c_size_t, C.c_void_p]
+        l.tg_gen_pg_backward.restype = C.c_int
         l.tg_profile_enable.argtypes = [C.c_int]
         l.tg_profile_enable.restype = None
         l.tg_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]

@@ -36,6 +36,28 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 
+def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1):
+    """tg_gen_pg_backward: gradients of sum(coeff-weighted log-probabilities of the targets) with respect to the
+    seven generator parameters (what autograd produces behind SeqGAN_G.batchPGLoss, models/SeqGAN_G.py:21-39).
+    Returns a tuple in GenW order: (emb, w_ih, w_hh, b_ih, b_hh, w_out, b_out)."""
+    w, keep = _lib.gen_weights(gen)
+    inp, _ = _tokens(inp, "inp")
+    target, _ = _tokens(target, "target")
+    N, L = inp.shape
+    dev = inp.device
+    shapes = [(w.V, w.E), (4 * w.H, w.E), (4 * w.H, w.H), (4 * w.H,), (4 * w.H,), (w.V, w.H), (w.V,)]
+    grads = [torch.empty(s, dtype=F32, device=dev) for s in shapes]
+    g = _lib.GenGrads(*[t.data_ptr() for t in grads])
+    nbytes = _lib.lib().tg_gen_pg_backward_workspace_bytes(C.byref(w), N, L)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    coeff = coeff.contiguous()
+    _lib.check(_lib.lib().tg_gen_pg_backward(
+        C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(target, I64, "target"),
+        _lib.dev_ptr(coeff, F32, "coeff"), _lib.dev_ptr(lse, F32, "lse"), _lib.dev_ptr(states, F32, "states"),
+        N, L, int(padding_idx), C.byref(g), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return tuple(grads)
+
+
 def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_lo=0, i_hi=None, out=None,
                 precision=None):
     """tg_gen_rollout: every rollout_mc_search(sentences, g) of get_reward's loops
