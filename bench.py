@@ -140,12 +140,92 @@ def bench_nll(args, dev):
     print(json.dumps(out))
 
 
+def bench_pg(args, dev):
+    """Side workload pg: the adversarial step's policy-gradient loss, forward + backward, at the
+    real-data generator shape (V5255 L51 E=H=32 B64) -- SeqGAN_G.batchPGLoss + loss.backward() of
+    instructor/real_data/seqgan_instructor.py:109-110 (the optimizer's own update is torch's and is not timed).
+    Beside it, on the same GPU, the reference's formulation in eager torch (nn.LSTM + Linear + log_softmax +
+    one_hot, what models/SeqGAN_G.py:21-39 executes) for the same inputs."""
+    V, L, E, H, B = 5255, 51, 32, 32, 64
+    gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=0.1, device=dev)
+    gen.name = "seqgan"
+    target = torch.from_numpy(tg.synth.tokens(31, (B, L), V)).to(dev)
+    inp = torch.cat([torch.ones(B, 1, dtype=torch.int64, device=dev), target[:, :-1]], 1)
+    reward = torch.from_numpy(tg.synth.uniform01(32, (B, L)).astype(np.float32)).to(dev)
+
+    def step():
+        loss = tg.pgloss.batchPGLoss(gen, inp, target, reward)
+        gen.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def eager_step():
+        h0 = torch.zeros(1, B, H, device=dev)
+        out, _ = gen.lstm(gen.embeddings(inp), (h0, h0.clone()))
+        logp = torch.log_softmax(gen.lstm2out(out.contiguous().view(-1, H)), -1).view(B, L, V)
+        onehot = torch.nn.functional.one_hot(target, V).float()
+        loss = -torch.sum(torch.sum(logp * onehot, -1) * reward)
+        gen.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def timed(fn, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+        eager_step()
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    dt = timed(step, args.steps)
+    prof = tg._lib.profile_read()
+    tg._lib.profile_enable(False)
+    dt_eager = timed(eager_step, args.steps)
+    fwd_ms = prof["gen_teacher"][0] / max(prof["gen_teacher"][1], 1) + \
+        prof["pg_forward"][0] / max(prof["pg_forward"][1], 1)
+    bwd_ms = prof["pg_backward"][0] / max(prof["pg_backward"][1], 1)
+    # backward: logits recomputed twice (row sweep, vocabulary sweep) + dh_proj + dW_out: 4 products of 2*H*V per
+    # token, plus 5 products of the cell's size through time
+    flops = (8 * H * V + 5 * 8 * H * (E + H)) * B * L
+    ach = flops / (bwd_ms * 1e-3) / 1e12
+    out = {"metric": "policy-gradient step sequences/sec", "value": B / dt, "unit": "sequences/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "batchPGLoss forward + backward: vocab 5255, len 51, emb/hidden 32, batch 64",
+                      "tokens_per_step": B * L},
+           "kernels": {"pg_forward (states + rows)": {"avg_ms": fwd_ms}, "pg_backward": {"avg_ms": bwd_ms}},
+           "torch_eager_same_gpu": {"ms_per_step": dt_eager * 1e3,
+                                    "what": "nn.LSTM + Linear + log_softmax + one_hot, forward + backward"},
+           "roofline": {"kernel": "pg_backward", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                        "flops_per_launch": flops, "avg_launch_ms": bwd_ms,
+                        "note": "3 264 token rows: a launch- and latency-bound size, far from the MFMA roof"}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        og = oracle.Gen(tg.synth.gen_state(V, E, H, seed=0, std=0.1))
+        a = [x.cpu().numpy() for x in (inp, target, reward)]
+        t0 = time.perf_counter()
+        oracle.pg_loss_grads(og, *a)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": B / t, "unit": "sequences/s", "cores": 1, "kind": "port",
+                               "sample": "one full step, numpy restatement (%.2f s; numpy's BLAS may use more "
+                                         "threads for the matrix products)" % t}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5", "pg"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
     ap.add_argument("--dis-precision", default=None, choices=["fp32", "split_f16"],
@@ -172,6 +252,10 @@ def main():
         if world > 1:
             raise SystemExit("workload c5 (NLL) is a single-GPU side measurement")
         return bench_nll(args, dev)
+    if args.workload == "pg":
+        if world > 1:
+            raise SystemExit("workload pg (policy-gradient step) is a single-GPU side measurement")
+        return bench_pg(args, dev)
     wl = WORKLOADS[args.workload]
     V, L, E, H, B = wl["V"], wl["L"], wl["E"], wl["H"], wl["B"]
     R = wl["R"] * world  # weak scaling: rollout_num 16 per GPU

@@ -250,6 +250,14 @@ typedef struct TgGenGrads {
     float* b_out;  /* [V]      */
 } TgGenGrads;
 size_t tg_gen_pg_backward_workspace_bytes(const TgGenWeights* w, int N, int L);
+/* Forward half for the same loss, shaped for an adversarial batch (few sequences): the cell-only pass of
+ * tg_gen_teacher_forced writes states_out [L+1,N,2,H] (required), then the projection, lse_out [N,L] and
+ * logp_out[n,t] = log_softmax(logits[n,t,:])[target[n,t]] are computed for all N*L rows side by side instead of
+ * step after step (LSTMGenerator.forward models/generator.py:40-60 + the one-hot pick of models/SeqGAN_G.py:35-36).
+ * Same results as tg_gen_teacher_forced to fp32 rounding.  E = H = 32 only. */
+int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp,
+                      const int64_t* target, int N, int L, float* logp_out,
+                      float* lse_out, float* states_out, void* stream);
 int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
                        const int64_t* target, const float* coeff,
                        const float* lse, const float* states, int N, int L,
@@ -277,6 +285,7 @@ int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
 #define TG_KERNEL_REDUCE 5        /* k_reward_reduce                              */
 #define TG_KERNEL_DIS_PREFIX 6    /* k_dis_conv<store-all> + k_dis_prefix_scan    */
 #define TG_KERNEL_PG_BACKWARD 7   /* k_pg_prep .. k_pg_reduce (one bracket)       */
+#define TG_KERNEL_PG_FORWARD 8    /* k_pg_fwd_rows                                */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

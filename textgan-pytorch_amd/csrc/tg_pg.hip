@@ -367,6 +367,82 @@ __global__ __launch_bounds__(256) void k_pg_bptt(const PgArgs a) {
     }
 }
 
+// Forward for few sequences (an adversarial batch is 64 x L): the persistent generator kernel walks the vocabulary
+// once per step and sequence tile, L steps in a row on two workgroups.  Teacher forcing does not need that order:
+// the states come from the cell-only pass of tg_gen_teacher_forced, and the projection, its log-sum-exp and the
+// target's logit are computed here for all N*L rows side by side -- 32 rows per workgroup, the four waves sharing
+// the vocabulary sweep, (max, sum) kept per lane and merged in fp64 at the end.
+__global__ __launch_bounds__(256) void k_pg_fwd_rows(const TgGenWeights wt, const int64_t* __restrict__ target,
+                                                     const float* __restrict__ states, int N, int L,
+                                                     float* __restrict__ logp_out, float* __restrict__ lse_out) {
+    __shared__ float sm_m[8][32], sm_s[8][32], sm_t[8][32];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, nl = lane & 31, hh = lane >> 5;
+    const int V = wt.V, NL = N * L, NTv = (V + 31) >> 5;
+    const int row = blockIdx.x * 32 + nl;
+    const int rc = tg_min(row, NL - 1);
+    const int n = rc / L, t = rc - n * L;
+    float hb[16];
+    load16(states + ((size_t)(t + 1) * N + n) * 2 * kHid + 16 * hh, hb);
+    const int my_t = clamp_tok(target[rc], V);
+    struct Frag { float a1[16]; f32x4 b[4]; };
+    auto load_frag = [&](int j, Frag& f) {
+        load16(wt.w_out + (size_t)tg_min(32 * j + nl, V - 1) * kHid + 16 * hh, f.a1);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int v0 = 32 * j + 8 * q + 4 * hh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) f.b[q][e] = wt.b_out[tg_min(v0 + e, V - 1)];
+        }
+    };
+    float m_run = TG_NEG_BIG, s_run = 0.f, lt = TG_NEG_BIG;
+    if (w < NTv) {
+        Frag cur;
+        load_frag(w, cur);
+        for (int j = w; j < NTv; j += 4) {
+            Frag nxt;
+            load_frag(tg_min(j + 4, NTv - 1), nxt);
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = TG_MFMA32(cur.a1[s], hb[s], acc);
+            float tmax = TG_NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int v = 32 * j + (r & 3) + 8 * (r >> 2) + 4 * hh;
+                const float l = acc[r] + cur.b[r >> 2][r & 3];
+                acc[r] = v < V ? l : TG_NEG_BIG;
+                lt = v == my_t ? l : lt;
+                tmax = __builtin_fmaxf(tmax, acc[r]);
+            }
+            const float m_new = __builtin_fmaxf(m_run, tmax);
+            float ts = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ts += tg_expf_neg(acc[r] - m_new);
+            s_run = s_run * tg_expf_neg(m_run - m_new) + ts;
+            m_run = m_new;
+            cur = nxt;
+        }
+    }
+    sm_m[2 * w + hh][nl] = m_run;
+    sm_s[2 * w + hh][nl] = s_run;
+    sm_t[2 * w + hh][nl] = lt;
+    __syncthreads();
+    if (tid < 32 && row < NL) {
+        float M = sm_m[0][tid], T = sm_t[0][tid];
+#pragma unroll
+        for (int p = 1; p < 8; ++p) { M = __builtin_fmaxf(M, sm_m[p][tid]); T = __builtin_fmaxf(T, sm_t[p][tid]); }
+        double S = 0.0;
+#pragma unroll
+        for (int p = 0; p < 8; ++p) S += (double)sm_s[p][tid] * exp((double)(sm_m[p][tid] - M));  // empty part: s = 0
+        const float lse = (float)((double)M + log(S));
+        if (lse_out) lse_out[row] = lse;
+        if (logp_out) logp_out[row] = T - lse;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_pg_reduce(const PgArgs a, int nwg) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= kPart) return;
@@ -423,6 +499,28 @@ bool shape_ok(const TgGenWeights* w, int N, int L) {
 }
 
 }  // namespace
+
+extern "C" int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                                 float* logp_out, float* lse_out, float* states_out, void* stream) {
+    if (!w || w->E != kHid || w->H != kHid) {
+        tg_set_error("tg_gen_pg_forward: only the E = H = 32 generator is supported");
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    if (!target || !states_out || (size_t)N * L >= ((size_t)1 << 31) - 64) {
+        tg_set_error("tg_gen_pg_forward: bad arguments (N=%d L=%d, target and states_out are required)", N, L);
+        return TG_ERR_ARG;
+    }
+    // states only: the cell pass of the generator kernel, no vocabulary projection (checks w, inp, N, L)
+    int rc = tg_gen_teacher_forced(w, inp, nullptr, N, L, nullptr, nullptr, nullptr, states_out, stream);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    tg_prof_begin(TG_KERNEL_PG_FORWARD, s);
+    hipLaunchKernelGGL(k_pg_fwd_rows, dim3((N * L + 31) / 32), dim3(256), 0, s, *w, target, states_out, N, L, logp_out,
+                       lse_out);
+    tg_prof_end(s);
+    return check_launch("k_pg_fwd_rows");
+}
 
 extern "C" size_t tg_gen_pg_backward_workspace_bytes(const TgGenWeights* w, int N, int L) {
     if (!shape_ok(w, N, L)) return 0;

@@ -36,6 +36,23 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 
+def gen_pg_forward(gen, inp, target):
+    """tg_gen_pg_forward: logp / lse / states of a teacher-forced pass, row-parallel projection (few sequences).
+    Same dict as gen_teacher_forced(want_lse=True, want_states=True)."""
+    w, keep = _lib.gen_weights(gen)
+    inp, _ = _tokens(inp, "inp")
+    target, _ = _tokens(target, "target")
+    N, L = inp.shape
+    dev = inp.device
+    logp = torch.empty(N, L, dtype=F32, device=dev)
+    lse = torch.empty(N, L, dtype=F32, device=dev)
+    states = torch.empty(L + 1, N, 2, w.H, dtype=F32, device=dev)
+    _lib.check(_lib.lib().tg_gen_pg_forward(
+        C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(target, I64, "target"), N, L,
+        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(states), _lib.stream_ptr()))
+    return {"logp": logp, "lse": lse, "logits": None, "states": states}
+
+
 def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1):
     """tg_gen_pg_backward: gradients of sum(coeff-weighted log-probabilities of the targets) with respect to the
     seven generator parameters (what autograd produces behind SeqGAN_G.batchPGLoss, models/SeqGAN_G.py:21-39).
