@@ -7,8 +7,9 @@
 // the logits tile by tile on the matrix cores:
 //     dlogits[n,t,v] = coeff[n,t] * (1[v == target[n,t]] - exp(logits[n,t,v] - lse[n,t])),   coeff = dLoss/dlogp
 //   k_pg_rows   one workgroup per 32 (n,t) rows, sweeps the vocabulary:   dh_proj = dlogits . W_out
-//   k_pg_vocab  one wave per 32 vocabulary entries, sweeps the rows:      dW_out = dlogits^T . h,  db_out
-//   k_pg_bptt   one workgroup per 32 sequences, t = L-1 .. 0: gates recomputed from the saved states, the
+//   k_pg_bptt_vocab, one launch, two kinds of workgroup:
+//     vocab     one workgroup per 32 vocabulary entries, sweeps the rows:  dW_out = dlogits^T . h,  db_out
+//     bptt      one workgroup per 32 sequences, t = L-1 .. 0: gates recomputed from the saved states, the
 //               recurrent and input gradients, and the weight gradients accumulated in MFMA registers
 //   k_pg_reduce fixed-order sum of the per-workgroup weight-gradient partials
 // Everything is fp32 on v_mfma_f32_32x32x2_f32 (exact products, fp32 accumulation).  Every MFMA operand comes
@@ -142,14 +143,16 @@ __global__ __launch_bounds__(256) void k_pg_rows(const PgArgs a) {
     }
 }
 
-// dW_out[v][k] = sum_rows dlogits[row][v] * h[row][k], db_out[v] = sum_rows dlogits[row][v].  One wave per 32
-// vocabulary entries (its W_out rows stay in registers as the B operand), sweeping the rows 32 at a time.  The
+// dW_out[v][k] = sum_rows dlogits[row][v] * h[row][k], db_out[v] = sum_rows dlogits[row][v].  One workgroup per 32
+// vocabulary entries (its W_out rows stay in registers as the B operand); its four waves share the sweep over the
+// rows, 32 at a time, and meet in LDS at the end.  The
 // logits tile lands as lane (v, hh) reg r <-> row 32rb + (r&3) + 8(r>>2) + 4hh, again the k order of the second
 // product; its A operand h[row][k] is read column-wise (16 dword loads, each 128 B across the lanes).
-__global__ __launch_bounds__(64) void k_pg_vocab(const PgArgs a) {
-    const int lane = threadIdx.x, vl = lane & 31, hh = lane >> 5;
+__device__ __forceinline__ void pg_vocab_body(const PgArgs& a, const int j, float (*red)[32][kLds], float (*redb)[kLds]) {
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, vl = lane & 31, hh = lane >> 5;
     const int V = a.w.V;
-    const int j = blockIdx.x;
     const int v = 32 * j + vl;
     const bool vok = v < V;
     const int vc = tg_min(v, V - 1);
@@ -181,10 +184,10 @@ __global__ __launch_bounds__(64) void k_pg_vocab(const PgArgs a) {
     float dbacc = 0.f;
     const int NRB = a.NLp >> 5;
     RB cur;
-    load_rb(0, cur);
-    for (int rb = 0; rb < NRB; ++rb) {
+    load_rb(tg_min(w, NRB - 1), cur);
+    for (int rb = w; rb < NRB; rb += 4) {  // the four waves share the row sweep
         RB nxt;
-        load_rb(tg_min(rb + 1, NRB - 1), nxt);
+        load_rb(tg_min(rb + 4, NRB - 1), nxt);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -203,13 +206,22 @@ __global__ __launch_bounds__(64) void k_pg_vocab(const PgArgs a) {
         cur = nxt;
     }
     const float db = dbacc + __shfl_xor(dbacc, 32);
-    if (vok) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 o = {acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(a.g.w_out + (size_t)v * kHid + 8 * q + 4 * hh) = o;
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 o = {acc2[4 * q], acc2[4 * q + 1], acc2[4 * q + 2], acc2[4 * q + 3]};
+        *reinterpret_cast<f32x4*>(&red[w][vl][8 * q + 4 * hh]) = o;
+    }
+    if (hh == 0) redb[w][vl] = db;
+    __syncthreads();
+    {   // fixed-order sum over the waves; thread -> (entry tid>>3, four columns)
+        const int v2 = tid >> 3, kc = tid & 7, vv = 32 * j + v2;
+        f32x4 o = *reinterpret_cast<const f32x4*>(&red[0][v2][4 * kc]);
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) o += *reinterpret_cast<const f32x4*>(&red[ww][v2][4 * kc]);
+        if (vv < V) {
+            *reinterpret_cast<f32x4*>(a.g.w_out + (size_t)vv * kHid + 4 * kc) = o;
+            if (kc == 0) a.g.b_out[vv] = redb[0][v2] + redb[1][v2] + redb[2][v2] + redb[3][v2];
         }
-        if (hh == 0) a.g.b_out[v] = db;
     }
 }
 
@@ -222,17 +234,14 @@ __global__ __launch_bounds__(64) void k_pg_vocab(const PgArgs a) {
 //     - transposed through LDS as the A operand of  da^T . x_t  and  da^T . h_{t-1}  (k = the 32 sequences),
 //       accumulated over all steps in two MFMA register tiles per wave;
 //     - summed over the sequences for the bias gradient.
-__global__ __launch_bounds__(256) void k_pg_bptt(const PgArgs a) {
-    __shared__ __attribute__((aligned(16))) float part_h[4][32][kLds];
-    __shared__ __attribute__((aligned(16))) float part_x[4][32][kLds];
-    __shared__ __attribute__((aligned(16))) float daT[4][32][kLds];
-    __shared__ __attribute__((aligned(16))) float xs[32][kLds];
-    __shared__ __attribute__((aligned(16))) float hs[32][kLds];
+__device__ __forceinline__ void pg_bptt_body(const PgArgs& a, const int blk, float (*part_h)[32][kLds],
+                                             float (*part_x)[32][kLds], float (*daT)[32][kLds], float (*xs)[kLds],
+                                             float (*hs)[kLds]) {
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, nl = lane & 31, hh = lane >> 5;
     const int N = a.N, L = a.L, V = a.w.V;
-    const int n = blockIdx.x * 32 + nl;
+    const int n = blk * 32 + nl;
     const bool valid = n < N;
     const int nc = tg_min(n, N - 1);
 
@@ -256,16 +265,29 @@ __global__ __launch_bounds__(256) void k_pg_bptt(const PgArgs a) {
     f32x4 dc = {0.f, 0.f, 0.f, 0.f}, dhrec = {0.f, 0.f, 0.f, 0.f};
     // the embedding-gradient scatter: thread -> (sequence tid>>3, four columns)
     const int n2 = tid >> 3, kc = tid & 7;
-    const int row2 = blockIdx.x * 32 + n2;
+    const int row2 = blk * 32 + n2;
 
-    for (int t = L - 1; t >= 0; --t) {
-        const int tok = clamp_tok(a.inp[(size_t)nc * L + t], V);
-        float xb[16], hb[16];
-        load16(a.w.emb + (size_t)tok * kHid + 16 * hh, xb);
+    // operands of a step, fetched one step ahead (the token two steps ahead): the step itself is a chain of
+    // dependent MFMAs and two barriers, there is nothing else to hide a gather behind
+    struct StepIn { float xb[16], hb[16]; f32x4 cprev, dh; };
+    auto load_step = [&](int t, int tok, StepIn& o) {
+        load16(a.w.emb + (size_t)tok * kHid + 16 * hh, o.xb);
         const float* sp = a.states + ((size_t)t * N + nc) * 2 * kHid;
-        load16(sp + 16 * hh, hb);
-        const f32x4 cprev = *reinterpret_cast<const f32x4*>(sp + kHid + 8 * w + 4 * hh);
-        f32x4 dh = *reinterpret_cast<const f32x4*>(a.dhproj + ((size_t)nc * L + t) * kHid + 8 * w + 4 * hh);
+        load16(sp + 16 * hh, o.hb);
+        o.cprev = *reinterpret_cast<const f32x4*>(sp + kHid + 8 * w + 4 * hh);
+        o.dh = *reinterpret_cast<const f32x4*>(a.dhproj + ((size_t)nc * L + t) * kHid + 8 * w + 4 * hh);
+    };
+    StepIn cur;
+    load_step(L - 1, clamp_tok(a.inp[(size_t)nc * L + L - 1], V), cur);
+    int tok_nxt = clamp_tok(a.inp[(size_t)nc * L + tg_max(L - 2, 0)], V);
+    for (int t = L - 1; t >= 0; --t) {
+        StepIn nxt;
+        load_step(tg_max(t - 1, 0), tok_nxt, nxt);
+        tok_nxt = clamp_tok(a.inp[(size_t)nc * L + tg_max(t - 2, 0)], V);
+        const float (&xb)[16] = cur.xb;
+        const float (&hb)[16] = cur.hb;
+        const f32x4 cprev = cur.cprev;
+        f32x4 dh = cur.dh;
         dh += dhrec;
         f32x16 acc = gbias;
 #pragma unroll
@@ -346,11 +368,12 @@ __global__ __launch_bounds__(256) void k_pg_bptt(const PgArgs a) {
             dWih = TG_MFMA32(aT[s], bx[s], dWih);
             dWhh = TG_MFMA32(aT[s], bh[s], dWhh);
         }
+        cur = nxt;
         __syncthreads();
     }
     // partials: D lane (column c = i, hh) reg r <-> local gate row jl = (r&3) + 8(r>>2) + 4hh of this wave, which is
     // (producer half jl>>4, producer reg jl&15) of the da layout
-    float* part = a.part + (size_t)blockIdx.x * kPart;
+    float* part = a.part + (size_t)blk * kPart;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int jl = (r & 3) + 8 * (r >> 2) + 4 * hh;
@@ -365,6 +388,18 @@ __global__ __launch_bounds__(256) void k_pg_bptt(const PgArgs a) {
         const int gr = (rj >> 2) * kHid + 8 * w + 4 * hj + (rj & 3);
         part[2 * 128 * kHid + gr] = db;
     }
+}
+
+// One launch for the two independent tails of the backward: the first nwg workgroups walk back through time
+// (two workgroups at batch 64, the long pole), the others sweep the rows for dW_out / db_out beside them.
+__global__ __launch_bounds__(256) void k_pg_bptt_vocab(const PgArgs a, const int nwg) {
+    __shared__ __attribute__((aligned(16))) float part_h[4][32][kLds];
+    __shared__ __attribute__((aligned(16))) float part_x[4][32][kLds];
+    __shared__ __attribute__((aligned(16))) float daT[4][32][kLds];
+    __shared__ __attribute__((aligned(16))) float xs[32][kLds];
+    __shared__ __attribute__((aligned(16))) float hs[32][kLds];
+    if ((int)blockIdx.x < nwg) pg_bptt_body(a, blockIdx.x, part_h, part_x, daT, xs, hs);
+    else pg_vocab_body(a, blockIdx.x - nwg, part_h, xs);
 }
 
 // Forward for few sequences (an adversarial batch is 64 x L): the persistent generator kernel walks the vocabulary
@@ -580,10 +615,8 @@ extern "C" int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp, con
     if ((rc = check_launch("k_pg_prep"))) return rc;
     hipLaunchKernelGGL(k_pg_rows, dim3(p.NLp / 32), dim3(256), 0, s, a);
     if ((rc = check_launch("k_pg_rows"))) return rc;
-    hipLaunchKernelGGL(k_pg_vocab, dim3(p.NTv), dim3(64), 0, s, a);
-    if ((rc = check_launch("k_pg_vocab"))) return rc;
-    hipLaunchKernelGGL(k_pg_bptt, dim3(p.nwg), dim3(256), 0, s, a);
-    if ((rc = check_launch("k_pg_bptt"))) return rc;
+    hipLaunchKernelGGL(k_pg_bptt_vocab, dim3(p.nwg + p.NTv), dim3(256), 0, s, a, p.nwg);
+    if ((rc = check_launch("k_pg_bptt_vocab"))) return rc;
     hipLaunchKernelGGL(k_pg_reduce, dim3((kPart + 255) / 256), dim3(256), 0, s, a, p.nwg);
     if ((rc = check_launch("k_pg_reduce"))) return rc;
     tg_prof_end(s);
