@@ -98,31 +98,36 @@ def cpu_baseline(wl, budget_s=15.0):
 
 def bench_nll(args, dev):
     """Side workload c5 (BASELINE configs[4]): NLL.cal_nll over 99 968 sequences (100 000 with drop_last at batch 64),
-    V5000 L20 E=H=32 -- one teacher-forced launch, fp32 throughout.  Not the headline metric: prints sequences/s."""
+    V5000 L20 E=H=32 -- one teacher-forced launch (tg_gen_nll) in --gen-precision (default: the library's,
+    split_f16).  Not the headline metric: prints sequences/s."""
     V, L, E, H, N, batch = 5000, 20, 32, 32, 99968, 64
     gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=1.0, device=dev)
     samples = torch.from_numpy(tg.synth.tokens(5, (N, L), V)).to(dev)
     for _ in range(args.warmup):
-        tg.nll.nll_of_samples(gen, samples, batch)
+        tg.nll.nll_of_samples(gen, samples, batch, precision=args.gen_precision)
     torch.cuda.synchronize()
     tg._lib.profile_enable(True)
     tg._lib.profile_read()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        nll, _pb = tg.nll.nll_of_samples(gen, samples, batch)
+        nll, _pb = tg.nll.nll_of_samples(gen, samples, batch, precision=args.gen_precision)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ms, n = tg._lib.profile_read()["gen_teacher"]
     tg._lib.profile_enable(False)
     flops = (2 * H * V + 8 * H * (E + H)) * N * L
     ach = flops / (ms / n * 1e-3) / 1e12
+    split = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16"
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     out = {"metric": "NLL sequences/sec", "value": N * args.steps / dt, "unit": "sequences/s", "n_gpus": 1,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "scaling": "weak", "vs_baseline": None, "dtype": "f16x3 (split fp32)" if split else "f32",
+           "data": "synthetic",
            "config": {"workload": "configs[4] NLL_gen over 99968 sequences: vocab 5000, len 20, emb/hidden 32, batch 64",
                       "tokens_per_step": N * L, "nll": nll},
-           "roofline": {"kernel": "gen_teacher", "bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+           "roofline": {"kernel": "gen_teacher", "bound": "mfma", "achieved": ach, "peak": peak,
+                        "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                        "mfma_products_per_flop": 3 if split else 1, "issued_frac": ach * (3 if split else 1) / peak,
                         "flops_per_launch": flops, "avg_launch_ms": ms / n}}
     if not args.no_cpu_baseline:
         from oracle import oracle

@@ -121,6 +121,17 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
                           float* states_out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * NLL pass: tg_gen_teacher_forced restricted to what NLL.cal_nll needs (metrics/nll.py:49-63: the log-probability
+ * of each target token), honouring w->precision.  With TG_GEN_SPLIT_F16 (E = H = 32) the log-sum-exp comes from
+ * the split-fp16 projection (probabilities within ~1e-6 relative of fp32) while the target's own logit is an exact
+ * fp32 dot product; with TG_GEN_FP32, or any other shape, the result is tg_gen_teacher_forced's, bit for bit.
+ *   logp_out [N,L] required; lse_out [N,L] or NULL; workspace of tg_gen_nll_workspace_bytes(w) (0 for fp32). */
+size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w);
+int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target,
+               int N, int L, float* logp_out, float* lse_out, void* workspace,
+               size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Monte-Carlo completions.
  * Replaces ROLLOUT.rollout_mc_search (utils/rollout.py:25-55) for every
  * (i, given_num) pair of ROLLOUT.get_reward's double loop (:143-145) in one

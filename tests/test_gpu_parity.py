@@ -59,9 +59,16 @@ def test_teacher_forced_logits_and_nll(name):
         np.testing.assert_allclose(lp[:8], c["logprobs"], rtol=1e-5, atol=2e-5)
     # the drop-in NLL surface: a loader of dicts, and the loader-free form
     loader = [{"input": inp[i:i + batch].cpu(), "target": tgt[i:i + batch].cpu()} for i in range(0, nb, batch)]
-    assert tg.nll.cal_nll(gen, loader) == pytest.approx(c["nll"], abs=1.01e-4)
-    val, _ = tg.nll.nll_of_samples(gen, tgt, batch, start_letter=1)
-    assert val == pytest.approx(c["nll"], abs=1.01e-4)
+    for prec in ("fp32", "split_f16"):  # tg_gen_nll; split takes effect at E = H = 32, other shapes run fp32
+        assert tg.nll.cal_nll(gen, loader, precision=prec) == pytest.approx(c["nll"], abs=1.01e-4)
+        val, pb = tg.nll.nll_of_samples(gen, tgt, batch, start_letter=1, precision=prec)
+        assert val == pytest.approx(c["nll"], abs=1.01e-4)
+        np.testing.assert_allclose(pb.cpu().numpy(), c["per_batch_loss"], rtol=1e-5)
+        lp2, lse2 = tg.ops.gen_nll(gen, inp, tgt, precision=prec, want_lse=True)
+        np.testing.assert_allclose(lp2.cpu().numpy(), c["logp_target"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(lse2.cpu().numpy(), o["lse"], rtol=1e-5, atol=1e-5)
+        if prec == "fp32" and not want_logits:  # (with logits_out the kernel takes its natural-log path)
+            assert torch.equal(lp2, r["logp"])  # the same kernel as tg_gen_teacher_forced
 
 
 def test_teacher_forced_ragged_rows():

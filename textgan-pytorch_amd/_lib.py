@@ -17,7 +17,7 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
            "tg_dis_workspace_bytes",
            "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
-           "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
+           "tg_gen_nll_workspace_bytes", "tg_gen_nll", "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
            "tg_reward_reduce",
            "tg_profile_enable", "tg_profile_read"]
 
@@ -84,6 +84,10 @@ def lib():
         l.tg_gen_pg_backward.argtypes = [C.c_void_p] * 6 + [C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p,
                                                            C.c_size_t, C.c_void_p]
         l.tg_gen_pg_backward.restype = C.c_int
+        l.tg_gen_nll_workspace_bytes.restype = C.c_size_t
+        l.tg_gen_nll_workspace_bytes.argtypes = [C.c_void_p]
+        l.tg_gen_nll.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
+        l.tg_gen_nll.restype = C.c_int
         l.tg_gen_pg_forward.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4
         l.tg_gen_pg_forward.restype = C.c_int
         l.tg_profile_enable.argtypes = [C.c_int]

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(WPE, W
 void k_gen(const GenArgs a) {
     static_assert(WPE == 2 || (WPE == 3 && SPLIT), "three waves per SIMD: split kernel only");
     constexpr bool kLean = WPE == 3;
-    static_assert(!SPLIT || (SAMPLE && REG), "the split-fp16 projection exists for the E = H = 32 sampling kernel");
+    static_assert(!SPLIT || REG, "the split-fp16 projection exists for the E = H = 32 kernels");
     constexpr int kH = 32 * HT;
     constexpr int kHStride = kH + 4;  // hbuf row stride (floats): 16-B aligned, conflict-free b128 reads
     static_assert(!REG || HT == 1, "register-resident operands need H = 32");
@@ -927,7 +927,7 @@ SamplerGeom make_geom(int V) {
 
 bool is_reg(int E, int H) { return E == 32 && H == 32; }
 
-// TG_GEN_SPLIT_F16 applies to the sampling kernel of the E = H = 32 shape; everything else computes in fp32
+// TG_GEN_SPLIT_F16 applies to the E = H = 32 shape (sampling kernels, tg_gen_nll); everything else computes in fp32
 bool use_split(const TgGenWeights& w) { return w.precision == TG_GEN_SPLIT_F16 && is_reg(w.E, w.H); }
 
 // bytes of the split-projection scratch: 256-B header (|max| bits, scales) + fragments
@@ -1016,6 +1016,9 @@ int launch(const GenArgs& a, int grid, hipStream_t stream) {
         if (a.frag) return grid >= 3 * 256 * 2 ? launch_t<true, 1, true, true, 3>(a, grid, stream)
                                                : launch_t<true, 1, true, true, 2>(a, grid, stream);
     }
+    if constexpr (!SAMPLE) {
+        if (a.frag && !a.logits_out) return launch_t<false, 1, true, true, 2>(a, grid, stream);  // tg_gen_nll
+    }
     if (is_reg(a.w.E, a.w.H)) return launch_t<SAMPLE, 1, true>(a, grid, stream);
     switch (a.w.H) {
         case 32: return launch_t<SAMPLE, 1, false>(a, grid, stream);
@@ -1056,6 +1059,40 @@ extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, 
     a.logits_out = logits_out;
     a.states_out = states_out;
     a.need_proj = ((target && logp_out) || lse_out || logits_out) ? 1 : 0;
+    return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
+}
+
+extern "C" size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w) {
+    return (w && use_split(*w)) ? split_bytes(make_geom(w->V)) : 0;
+}
+
+extern "C" int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                          float* logp_out, float* lse_out, void* workspace, size_t workspace_bytes, void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!inp || !target || !logp_out || N < 0 || L < 1) {
+        tg_set_error("tg_gen_nll: bad arguments (N=%d L=%d)", N, L);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    GenArgs a = {};
+    a.w = *w;
+    a.geo = make_geom(w->V);
+    a.N = N;
+    a.L = L;
+    a.inp = inp;
+    a.target = target;
+    a.logp_out = logp_out;
+    a.lse_out = lse_out;
+    a.need_proj = 1;
+    if (use_split(*w)) {
+        if (!workspace || workspace_bytes < tg_gen_nll_workspace_bytes(w)) {
+            tg_set_error("tg_gen_nll: workspace too small (%zu < %zu)", workspace_bytes, tg_gen_nll_workspace_bytes(w));
+            return TG_ERR_WORKSPACE;
+        }
+        rc = prepare_split(a, workspace, (hipStream_t)stream);
+        if (rc) return rc;
+    }
     return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
 }
 

@@ -36,6 +36,24 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 
+def gen_nll(gen, inp, target, precision=None, want_lse=False):
+    """tg_gen_nll: log-probabilities of the targets under teacher forcing (metrics/nll.py:59-61), in the
+    library's default generator arithmetic or ``precision``.  Returns logp [N,L] (and lse if asked)."""
+    w, keep = _lib.gen_weights(gen, precision)
+    inp, _ = _tokens(inp, "inp")
+    target, _ = _tokens(target, "target")
+    N, L = inp.shape
+    dev = inp.device
+    logp = torch.empty(N, L, dtype=F32, device=dev)
+    lse = torch.empty(N, L, dtype=F32, device=dev) if want_lse else None
+    nbytes = _lib.lib().tg_gen_nll_workspace_bytes(C.byref(w))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    _lib.check(_lib.lib().tg_gen_nll(
+        C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(target, I64, "target"), N, L,
+        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return (logp, lse) if want_lse else logp
+
+
 def gen_pg_forward(gen, inp, target):
     """tg_gen_pg_forward: logp / lse / states of a teacher-forced pass, row-parallel projection (few sequences).
     Same dict as gen_teacher_forced(want_lse=True, want_states=True)."""
