@@ -29,6 +29,22 @@ def one(pattern):
     return files[0]
 
 
+def stats_rows(stats_dir):
+    """Per-kernel statistics from rocprofv3 --kernel-trace --stats output: the csv when it was asked for
+    (--output-format csv), else computed from the kernels view of the default sqlite file (*_results.db)."""
+    files = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)
+    if files:
+        return list(csv.DictReader(open(files[0])))
+    import sqlite3
+    db = sqlite3.connect(one(os.path.join(stats_dir, "**", "*_results.db")))
+    q = ("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+         "group by name order by sum(duration) desc")
+    got = list(db.execute(q))
+    total = float(sum(r[2] for r in got)) or 1.0
+    return [{"Name": r[0], "Calls": r[1], "TotalDurationNs": r[2], "AverageNs": "%.1f" % r[3],
+             "Percentage": "%.2f" % (100.0 * r[2] / total), "MinNs": r[4], "MaxNs": r[5]} for r in got]
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     workload = "c2"
@@ -37,7 +53,7 @@ def main():
         args.remove(workload)
     tag, stats_dir = args[0], args[1]
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
-    rows = list(csv.DictReader(open(one(os.path.join(stats_dir, "**", "*kernel_stats.csv")))))
+    rows = stats_rows(stats_dir)
     with open(os.path.join(ROOT, "profiles", tag + "_kernel_stats.csv"), "w") as f:
         wr = csv.writer(f)
         wr.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs"])
