@@ -74,7 +74,11 @@ def cpu_baseline(wl, budget_s=15.0):
     bounded sample of the same workload: same shapes, rollout_num reduced to fit ~budget_s."""
     from oracle import oracle
     V, L, B = wl["V"], wl["L"], wl["B"]
-    gsd = tg.synth.gen_state(V, wl["E"], wl["H"], seed=0, std=1.0)
+    # bound the sample for the scaled config: fewer sentences (the path is row-parallel; the rate per completion
+    # does not depend on the batch), sized for ~budget_s at an assumed 50 GFLOP/s of host arithmetic
+    per_completion = (2 * wl["H"] * V + 8 * wl["H"] * (wl["E"] + wl["H"])) * (L - 1) / 2 + 80e6
+    B = int(min(B, max(2, budget_s * 5e10 / (L * per_completion))))
+    gsd = tg.synth.gen_state(V, wl["E"], wl["H"], seed=0, std=1.0 if wl["H"] == 32 else 0.05)
     if wl.get("dis") == "sentigan":
         dsd = tg.synth.dis_state(V, 64, *tg.synth.SENTIGAN_D_FILTERS, n_out=5, seed=0)
     else:
@@ -93,7 +97,7 @@ def cpu_baseline(wl, budget_s=15.0):
     R = int(max(1, min(wl["R"], budget_s / max(t1, 1e-3))))
     t = run(R) if R > 1 else t1
     return {"value": R * L * B / t, "unit": "completions/s", "cores": oracle.num_threads(), "kind": "port",
-            "sample": "same workload at rollout_num %d (%d completions, %.1f s)" % (R, R * L * B, t)}
+            "sample": "same workload at batch %d, rollout_num %d (%d completions, %.1f s)" % (B, R, R * L * B, t)}
 
 
 def bench_nll(args, dev):
@@ -323,23 +327,28 @@ def main():
         gsplit = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and E == 32 and H == 32
         # flops one launch EXECUTES (prefix-reuse conv: fresh windows only); the reference-equivalent conv work
         # (every window of every completion) is reported beside it
-        per_launch = {"dis_conv": conv_fresh_bi * B * wl["R"], "dis_highway": hw_f * n_local,
-                      "gen_sample": gen_f * B * wl["R"] * L * (L - 1) // 2}
-        peaks = {"dis_conv": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
-                 "dis_highway": PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS,
-                 "gen_sample": PEAK_F16_MFMA_TFLOPS if gsplit else PEAK_FP32_MFMA_TFLOPS}
+        gwide = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and not (E == 32 and H == 32)
+        draws = B * wl["R"] * L * (L - 1) // 2            # sampled tokens of one rank's call
+        cell_steps = B * wl["R"] * (L - 1) * (L - 2) // 2  # wide path: rows enter with their prefix state, no cell step
+        # flops one rank EXECUTES per get_reward call, per kernel (prefix-reuse conv: fresh windows only; the
+        # reference-equivalent conv work, every window of every completion, is reported beside it)
+        per_call = {"dis_conv": conv_fresh_bi * B * wl["R"], "dis_highway": hw_f * n_local,
+                    "gen_sample": gen_f * draws, "genw_proj": 2 * H * V * draws, "genw_cell": 8 * H * (E + H) * cell_steps}
+        f16 = {"dis_conv": split, "dis_highway": split, "gen_sample": gsplit, "genw_proj": True, "genw_cell": True}
+        peaks = {k: PEAK_F16_MFMA_TFLOPS if v else PEAK_FP32_MFMA_TFLOPS for k, v in f16.items()}
         # split-f16 kernels issue three fp16 MFMA products per algorithmic multiply-add
-        issue_factor = {"dis_conv": 3 if split else 1, "dis_highway": 3 if split else 1,
-                        "gen_sample": 3 if gsplit else 1}
+        issue_factor = {k: 3 if v else 1 for k, v in f16.items()}
         kernels = {}
+        calls = args.steps * k_gens
         for name, (ms, n) in prof.items():
             if n:
-                kernels[name] = {"avg_ms": ms / n, "launches": n}
-                if name in per_launch:
-                    kernels[name]["tflops"] = per_launch[name] / (ms / n * 1e-3) / 1e12
+                kernels[name] = {"avg_ms": ms / n, "launches": n, "ms_per_call": ms / calls}
+                if name in per_call:
+                    kernels[name]["tflops"] = per_call[name] * calls / (ms * 1e-3) / 1e12
                     kernels[name]["peak_tflops"] = peaks[name]
                     kernels[name]["mfma_products_per_flop"] = issue_factor[name]
-        kernels["dis_conv"]["reference_equivalent_tflops"] = conv_f * n_local / (kernels["dis_conv"]["avg_ms"] * 1e-3) / 1e12
+        kernels["dis_conv"]["reference_equivalent_tflops"] = conv_f * n_local / (kernels["dis_conv"]["ms_per_call"] * 1e-3) / 1e12
+        per_launch = {k: v * calls / kernels[k]["launches"] for k, v in per_call.items() if k in kernels}
         dom = max(per_launch, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
         ach = kernels[dom]["tflops"]
         out = {
@@ -347,8 +356,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" + (" (split-f16 x3 operands, f32 accumulate: %s)" % ", ".join(
-                (["generator projection"] if gsplit else []) + (["scorer conv/highway"] if split else []))
-                if (split or gsplit) else ""), "data": "synthetic",
+                (["generator projection"] if gsplit else []) + (["generator gates and projection"] if gwide else []) +
+                (["scorer conv/highway"] if split else []))
+                if (split or gsplit or gwide) else ""), "data": "synthetic",
             "config": {"workload": "%s: vocab %d, len %d, emb/hidden %d, batch %d, rollout_num %d per GPU (%d total), "
                                    "%s scorer%s" % (wl["desc"], V, L, H, B, wl["R"], R, dis_kind,
                                                     " eval mode" if args.eval_mode else " with live dropout"),

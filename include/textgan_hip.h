@@ -54,8 +54,10 @@ typedef struct TgGenWeights {
  *   TG_GEN_FP32       exact fp32 (v_mfma_f32_32x32x2_f32)
  *   TG_GEN_SPLIT_F16  operands scaled by a power of two and split into fp16 hi + lo (22 mantissa bits), three
  *                     fp16 MFMAs per product with fp32 accumulation, bias added exactly; logits move by ~1e-6.
- *                     Takes effect for E = H = 32 (every SeqGAN / SentiGAN config of the reference); other
- *                     shapes compute in fp32. */
+ *                     E = H = 32 (every SeqGAN / SentiGAN config of the reference): inside the persistent kernel.
+ *                     Other shapes (E, H multiples of 32, V <= 32768 -- the scaled config): tg_gen_rollout and
+ *                     tg_gen_sample run step-synchronous split-fp16 GEMMs for the gates and the projection
+ *                     (tg_genw.hip); tg_gen_teacher_forced / tg_gen_nll stay fp32 there. */
 #define TG_GEN_FP32 0
 #define TG_GEN_SPLIT_F16 1
 
@@ -148,12 +150,13 @@ int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target,
  *                            drawn token is still what is written, but the
  *                            token fed to the next step is forced[...], so one
  *                            fp32 CDF tie does not cascade down the row.
- *   workspace   prefix states (+ the split projection's W_out fragments),
- *               tg_gen_rollout_workspace_bytes(w,B,L) bytes.
+ *   workspace   prefix states (+ the split projection's W_out fragments; shapes beyond E = H = 32 in
+ *               TG_GEN_SPLIT_F16: operand fragments, per-row state and sampler records of one chunk of rows),
+ *               tg_gen_rollout_workspace_bytes(w,B,L,i_hi-i_lo) bytes.
  * Sampling is inverse-CDF in the canonical order documented in DESIGN.md
  * ("canonical sampler") -- it replaces torch.multinomial(exp(out),1)
  * (utils/rollout.py:49). */
-size_t tg_gen_rollout_workspace_bytes(const TgGenWeights* w, int B, int L);
+size_t tg_gen_rollout_workspace_bytes(const TgGenWeights* w, int B, int L, int R /* rollout indices of the call: i_hi - i_lo */);
 int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B,
                    int L, int R, int g_lo, int g_hi, int i_lo, int i_hi,
                    const float* uniforms, const int64_t* forced,
@@ -167,8 +170,8 @@ int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B,
  *   uniforms [L,N] fp32: draw for row n at position t is uniforms[t*N + n]
  *   forced   [N,L] int64 or NULL (replay mode, as in tg_gen_rollout)
  *   out      [N,L] int64
- *   workspace  tg_gen_sample_workspace_bytes(w) bytes (0 for TG_GEN_FP32: may be NULL) */
-size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w);
+ *   workspace  tg_gen_sample_workspace_bytes(w, N) bytes (0 for TG_GEN_FP32: may be NULL) */
+size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w, int N);
 int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
                   const float* uniforms, const int64_t* forced, int64_t* out,
                   void* workspace, size_t workspace_bytes, void* stream);
@@ -297,6 +300,9 @@ int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
 #define TG_KERNEL_DIS_PREFIX 6    /* k_dis_conv<store-all> + k_dis_prefix_scan    */
 #define TG_KERNEL_PG_BACKWARD 7   /* k_pg_prep .. k_pg_reduce (one bracket)       */
 #define TG_KERNEL_PG_FORWARD 8    /* k_pg_fwd_rows                                */
+#define TG_KERNEL_GENW_CELL 9     /* k_genw_gemm<cell>: gates GEMM + state update  */
+#define TG_KERNEL_GENW_PROJ 10    /* k_genw_gemm<proj>: vocabulary GEMM + records  */
+#define TG_KERNEL_GENW_DRAW 11    /* k_genw_draw                                   */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

@@ -89,7 +89,7 @@ def test_teacher_forced_ragged_rows():
 
 
 # ------------------------------------------------------------------ generator, sampling
-GEN_PRECISIONS = ["fp32", "split_f16"]  # TG_GEN_*: split applies to E = H = 32, other shapes run fp32 either way
+GEN_PRECISIONS = ["fp32", "split_f16"]  # TG_GEN_*: E = H = 32 inside the persistent kernel, other shapes tg_genw.hip
 
 
 @pytest.mark.parametrize("precision", GEN_PRECISIONS)
@@ -145,6 +145,74 @@ def test_rollout_subranges_and_mc_search():
     one = ro.rollout_mc_search(_t(sent), 4, uniforms=_t(u[:1]))
     assert torch.equal(one, full[0, 3])
     assert torch.equal(full[:, L - 1], _t(sent).expand(R, B, L))  # given_num == L is the sentence itself
+
+
+# ------------------------------------------------------------------ generator beyond E = H = 32 (tg_genw.hip)
+WIDE_CASES = [
+    # V, E, H, B, L, R, std -- the canonical sampler has more than 16 groups per span above V = 16384, B*R*L and V
+    # are ragged against the 128-wide GEMM tiles, E != H
+    (20011, 64, 64, 5, 7, 3, 0.3),
+    (32000, 32, 128, 8, 6, 2, 0.2),
+    (1500, 96, 32, 40, 9, 4, 0.5),
+    (4099, 512, 512, 3, 5, 2, 0.05),
+]
+
+
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+@pytest.mark.parametrize("V,E,H,B,L,R,std", WIDE_CASES)
+def test_rollout_wide_shapes_against_oracle(V, E, H, B, L, R, std, precision):
+    """Shapes outside the E = H = 32 kernels: split_f16 runs the step-synchronous GEMM path (cell and projection
+    on split-fp16 MFMAs, per-tile sampler records), fp32 the generic persistent kernel.  Step-wise token parity with
+    the oracle (>= 99.9 %, disagreements only at CDF ties), prefix copies exact, sub-ranges equal to the full call."""
+    gsd = synth.gen_state(V, E, H, seed=11, std=std)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    sent, u = synth.tokens(21, (B, L), V), synth.uniform01(22, (R, L, L, B))
+    ref = oracle.gen_rollout(og, sent, R, u)
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision=precision)
+    prof = tg._lib.profile_read()
+    tg._lib.profile_enable(False)
+    wide = precision == "split_f16"  # which kernels served the call
+    assert (prof["genw_proj"][1] > 0) == wide and (prof["genw_draw"][1] > 0) == wide and (prof["gen_sample"][1] > 0) != wide
+    _cases.check_token_parity(replay.cpu().numpy(), ref, u, og, max_check=20)
+    free = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), precision=precision)
+    assert (free.cpu().numpy() == ref).all(-1).mean() >= 0.97
+    part = torch.full_like(free, -1)
+    tg.ops.gen_rollout(gen, _t(sent), R, _t(u), g_lo=2, g_hi=4, i_lo=1, i_hi=R, out=part, precision=precision)
+    assert torch.equal(part[1:, 1:4], free[1:, 1:4])
+    assert (part[0] == -1).all() and (part[1:, :1] == -1).all() and (part[1:, 4:] == -1).all()
+
+
+@pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1)])
+def test_sample_wide_shapes_against_oracle(V, E, H, N, L, std):
+    gsd = synth.gen_state(V, E, H, seed=12, std=std)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    u = synth.uniform01(23, (L, N))
+    ref = oracle.gen_sample(og, N, L, 1, u)
+    for precision in GEN_PRECISIONS:
+        out = tg.ops.gen_sample(gen, N, L, 1, _t(u), forced=_t(ref), precision=precision).cpu().numpy()
+        assert (out == ref).mean() >= 0.999
+        free = tg.ops.gen_sample(gen, N, L, 1, _t(u), precision=precision).cpu().numpy()
+        assert (free == ref).all(-1).mean() >= 0.97
+
+
+@pytest.mark.parametrize("std,emb_scale,bias_scale", [(0.01, 1.0, 1.0), (2.0, 1.0, 1.0), (0.3, 1e-3, 30.0), (0.3, 50.0, 1.0)])
+def test_wide_generator_across_weight_scales(std, emb_scale, bias_scale):
+    """The wide path scales W_out, W_ih, W_hh and the embedding table by powers of two taken from their |max| and
+    shares one scale between the two products of the cell: parity has to hold when the tensors' ranges differ."""
+    V, E, H, B, L, R = 3000, 64, 128, 16, 8, 2
+    gsd = {k: np.array(v) for k, v in synth.gen_state(V, E, H, seed=13, std=std).items()}
+    gsd["embeddings.weight"] = (gsd["embeddings.weight"] * emb_scale).astype(np.float32)
+    gsd["lstm2out.bias"] = (gsd["lstm2out.bias"] * bias_scale).astype(np.float32)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    sent, u = synth.tokens(1, (B, L), V), synth.uniform01(2, (R, L, L, B))
+    ref = oracle.gen_rollout(og, sent, R, u)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision="split_f16").cpu().numpy()
+    _cases.check_token_parity(replay, ref, u, og, max_check=20)
 
 
 # ------------------------------------------------------------------ discriminator

@@ -22,7 +22,7 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_profile_enable", "tg_profile_read"]
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
-           "dis_prefix": 6, "pg_backward": 7, "pg_forward": 8}
+           "dis_prefix": 6, "pg_backward": 7, "pg_forward": 8, "genw_cell": 9, "genw_proj": 10, "genw_draw": 11}
 
 
 class GenW(C.Structure):
@@ -58,9 +58,9 @@ def lib():
         l.tg_version.restype = C.c_char_p
         l.tg_last_error.restype = C.c_char_p
         l.tg_gen_rollout_workspace_bytes.restype = C.c_size_t
-        l.tg_gen_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.tg_gen_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.tg_gen_sample_workspace_bytes.restype = C.c_size_t
-        l.tg_gen_sample_workspace_bytes.argtypes = [C.c_void_p]
+        l.tg_gen_sample_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
         l.tg_dis_workspace_bytes.restype = C.c_size_t
         l.tg_dis_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.tg_gen_teacher_forced.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5

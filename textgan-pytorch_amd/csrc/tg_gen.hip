@@ -26,6 +26,7 @@
 #include <type_traits>
 
 #include "tg_common.h"
+#include "tg_genw.h"
 
 namespace {
 
@@ -652,19 +653,24 @@ void k_gen(const GenArgs a) {
             // the running max of a span settles early: consecutive records mostly share their scale factor
             double s = 0.0, fac = 1.0;
             float fx = M;
-            float2 rq[16];  // NG <= 16: all reads in flight before the (sequential, fp64) sum starts
+            // batches of 16 groups (one batch up to V = 16384; GK stops at 8, so larger vocabularies have more groups)
+#pragma unroll 1
+            for (int qb = 0; qb < ng_valid; qb += 16) {
+                float2 rq[16];  // all reads of a batch in flight before the (sequential, fp64) sum starts
 #pragma unroll
-            for (int q = 0; q < 16; ++q) rq[q] = rec[(tg_min(q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
+                for (int q = 0; q < 16; ++q)
+                    rq[q] = rec[(tg_min(qb + q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                if (q < ng_valid) {
-                    const float2 r = rq[q];
-                    if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
-                    const double c = (double)r.y * fac;
-                    s += c;
-                    // the record is only read again by the group search below, which wants this product: leave it in
-                    // place of the (max, sum) pair (same 8 bytes, same owner thread)
-                    reinterpret_cast<double*>(rec)[(q * kNSpan + sp) * kRows + n] = c;
+                for (int q = 0; q < 16; ++q) {
+                    if (qb + q < ng_valid) {
+                        const float2 r = rq[q];
+                        if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
+                        const double c = (double)r.y * fac;
+                        s += c;
+                        // the record is only read again by the group search below, which wants this product: leave it
+                        // in place of the (max, sum) pair (same 8 bytes, same owner thread)
+                        reinterpret_cast<double*>(rec)[((qb + q) * kNSpan + sp) * kRows + n] = c;
+                    }
                 }
             }
             sbuf[sp * kRows + n] = s;
@@ -685,16 +691,19 @@ void k_gen(const GenArgs a) {
             }
             if (sel == sp) {  // exactly one of the row's 8 threads owns the draw
                 int gq = ng_valid - 1;
-                double cq[16];  // the groups' contributions at the row's scale, left by the span-sum pass
-#pragma unroll
-                for (int q = 0; q < 16; ++q)
-                    cq[q] = reinterpret_cast<const double*>(rec)[(tg_min(q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
                 bool found = false;
+#pragma unroll 1
+                for (int qb = 0; qb < ng_valid && !found; qb += 16) {
+                    double cq[16];  // the groups' contributions at the row's scale, left by the span-sum pass
 #pragma unroll
-                for (int q = 0; q < 16; ++q) {
-                    if (q < ng_valid && !found) {
-                        if (p + cq[q] > target || q == ng_valid - 1) { gq = q; found = true; }
-                        else p += cq[q];
+                    for (int q = 0; q < 16; ++q)
+                        cq[q] = reinterpret_cast<const double*>(rec)[(tg_min(qb + q, tg_max(ng_valid - 1, 0)) * kNSpan + sp) * kRows + n];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        if (qb + q < ng_valid && !found) {
+                            if (p + cq[q] > target || qb + q == ng_valid - 1) { gq = qb + q; found = true; }
+                            else p += cq[q];
+                        }
                     }
                 }
                 selv[n] = sp_lo + gq * EG;
@@ -1100,12 +1109,14 @@ static size_t states_bytes(int B, int L, int H) {
     return (sizeof(float) * (size_t)(L + 1) * B * 2 * H + 255) / 256 * 256;
 }
 
-extern "C" size_t tg_gen_rollout_workspace_bytes(const TgGenWeights* w, int B, int L) {
+extern "C" size_t tg_gen_rollout_workspace_bytes(const TgGenWeights* w, int B, int L, int R) {
     if (!w || B < 1 || L < 1) return 0;
+    if (tg_genw_applies(w)) return states_bytes(B, L, w->H) + tg_genw_rollout_workspace_bytes(w, B, L, R);
     return states_bytes(B, L, w->H) + (use_split(*w) ? split_bytes(make_geom(w->V)) : 0);
 }
 
-extern "C" size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w) {
+extern "C" size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w, int N) {
+    if (w && tg_genw_applies(w)) return tg_genw_sample_workspace_bytes(w, N);
     return (w && use_split(*w)) ? split_bytes(make_geom(w->V)) : 0;
 }
 
@@ -1121,14 +1132,20 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
         return TG_ERR_ARG;
     }
     if (i_lo == i_hi) return TG_OK;
-    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(w, B, L)) {
+    if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(w, B, L, i_hi - i_lo)) {
         tg_set_error("tg_gen_rollout: workspace too small (%zu < %zu)", workspace_bytes,
-                     tg_gen_rollout_workspace_bytes(w, B, L));
+                     tg_gen_rollout_workspace_bytes(w, B, L, i_hi - i_lo));
         return TG_ERR_WORKSPACE;
     }
     // 1) prefix states: teacher-forced pass over the sentences, no projection (rollout.py:35-38)
     rc = tg_gen_teacher_forced(w, sentences, nullptr, B, L, nullptr, nullptr, nullptr, (float*)workspace, stream);
     if (rc) return rc;
+    if (tg_genw_applies(w)) {  // shapes beyond E = H = 32 in split-fp16: step-synchronous GEMMs (tg_genw.hip)
+        const size_t sb = states_bytes(B, L, w->H);
+        return tg_genw_rollout(w, sentences, B, L, g_lo, g_hi, i_lo, i_hi, uniforms, forced, completions,
+                               (const float*)workspace, reinterpret_cast<char*>(workspace) + sb, workspace_bytes - sb,
+                               (hipStream_t)stream);
+    }
     // 2) all completions; tiles ordered by given_num ascending (longest first)
     GenArgs a = {};
     a.w = *w;
@@ -1169,6 +1186,8 @@ extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;
+    if (tg_genw_applies(w))
+        return tg_genw_sample(w, N, L, start_letter, uniforms, forced, out, workspace, workspace_bytes, (hipStream_t)stream);
     GenArgs a = {};
     a.w = *w;
     a.geo = make_geom(w->V);
@@ -1180,9 +1199,9 @@ extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_
     a.N = N;
     a.L = L;
     if (use_split(*w)) {
-        if (!workspace || workspace_bytes < tg_gen_sample_workspace_bytes(w)) {
+        if (!workspace || workspace_bytes < tg_gen_sample_workspace_bytes(w, N)) {
             tg_set_error("tg_gen_sample: workspace too small (%zu < %zu)", workspace_bytes,
-                         tg_gen_sample_workspace_bytes(w));
+                         tg_gen_sample_workspace_bytes(w, N));
             return TG_ERR_WORKSPACE;
         }
         rc = prepare_split(a, workspace, (hipStream_t)stream);

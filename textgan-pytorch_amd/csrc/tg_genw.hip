@@ -1,0 +1,900 @@
+// K-GENW: the LSTM generator for shapes beyond E = H = 32 (the scaled config: V 32k, E = H = 512,
+// millions of completions) as step-synchronous GEMMs on split-fp16 MFMAs (gfx950).
+//
+// At H = 512 the gate weights (8 MB) and W_out (65 MB) cannot live in a workgroup, so the per-row-tile
+// persistent kernel of tg_gen.hip re-streams them for every 32 rows.  Here all rows of a chunk advance one
+// timestep together and each step is three launches over the rows that are active at it:
+//   k_genw_gemm<CELL>  gates[4H x rows] = [W_ih|W_hh] . [x;h]   (+ bias, sigmoid/tanh, c and h update)
+//   k_genw_gemm<PROJ>  logits[V x rows] = W_out . h (+ bias), per 16-entry tile a (max, sum 2^(l-max))
+//                      record -- logits never reach HBM
+//   k_genw_draw        canonical inverse-CDF draw from the records; only the 16
+//                      logits of the chosen tile are recomputed
+// Both GEMMs: 128 x 128 tile, K steps of 32 through LDS (two buffers, one barrier per step, next step's
+// operands in flight in registers), 4 waves x (2 x 2) 32x32x16 fp16 MFMA tiles, three products per
+// operand pair (hi.hi + hi.lo + lo.hi, fp32 accumulation) exactly as the split arithmetic of tg_gen.hip /
+// tg_dis.hip.  Every operand is kept in HBM in MFMA fragment order ("piece" = the 16 B one lane feeds to
+// one MFMA), so staging is a linear copy and every LDS read is a conflict-free 1-KiB row.
+// Replaces models/generator.py:40-84 and utils/rollout.py:25-55 of the reference for those shapes.
+#include <type_traits>
+
+#include "tg_common.h"
+#include "tg_genw.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+#define TG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+constexpr float kHScale = 8192.f;  // h in (-1, 1) -> below 2^13 in fp16
+constexpr float kL2E = 1.44269502162933349609375f;
+constexpr int kChunkRows = 1 << 18;  // rows (completions) advanced together
+constexpr int kMaxNG = 32;           // groups per span the draw kernel holds in registers (V <= 32768)
+
+struct Scales {  // device side, written by k_genw_prep
+    float sWout, invProj;  // W_out*log2(e) scale, 1/(sWout * kHScale)
+    float sI, sX, sHH, invCell;
+};
+
+struct Geom {
+    int V, E, H;
+    int KBh, KBe, KBc;    // 16-wide k blocks of H, E, E+H
+    int MBp;              // 32-entry vocab blocks, padded to whole 128-entry tiles
+    int NT16;             // ceil(V/16): 16-entry tiles that hold vocabulary
+    int Ls, NT, GK, NG;   // canonical sampler geometry (tg_gen.hip make_geom / oracle orc_span_len)
+};
+
+Geom make_geom(const TgGenWeights& w) {
+    Geom g;
+    g.V = w.V; g.E = w.E; g.H = w.H;
+    g.KBh = w.H / 16; g.KBe = w.E / 16; g.KBc = g.KBh + g.KBe;
+    g.MBp = 4 * ((w.V + 127) / 128);
+    g.NT16 = (w.V + 15) / 16;
+    g.Ls = 16 * ((w.V + 127) / 128);
+    g.NT = g.Ls / 16;
+    g.GK = 1;
+    while ((g.NT + g.GK - 1) / g.GK > 16 && g.GK < 8) g.GK *= 2;
+    g.NG = (g.NT + g.GK - 1) / g.GK;
+    return g;
+}
+
+size_t al256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct Carve {  // workspace layout
+    unsigned* absmax; Scales* sc; float* bias2; float* gb;
+    f32x4* a_proj; f32x4* a_cell; _Float16* emb_hi; _Float16* emb_lo;
+    f32x4* hfrag[2]; f32x4* cfrag; float2* rec; int* tok;
+    size_t bytes;
+};
+
+Carve carve(const Geom& g, size_t rowsP, void* base) {
+    Carve c;
+    char* p = reinterpret_cast<char*>(base);
+    size_t o = 0;
+    auto take = [&](size_t n) { char* q = p + o; o += al256(n); return q; };
+    c.absmax = reinterpret_cast<unsigned*>(take(256));
+    c.sc = reinterpret_cast<Scales*>(reinterpret_cast<char*>(c.absmax) + 64);
+    c.bias2 = reinterpret_cast<float*>(take(sizeof(float) * g.MBp * 32));
+    c.gb = reinterpret_cast<float*>(take(sizeof(float) * 4 * g.H));
+    c.a_proj = reinterpret_cast<f32x4*>(take((size_t)g.MBp * g.KBh * 128 * 16));
+    c.a_cell = reinterpret_cast<f32x4*>(take((size_t)(4 * g.H / 32) * g.KBc * 128 * 16));
+    c.emb_hi = reinterpret_cast<_Float16*>(take((size_t)g.V * g.E * 2));
+    c.emb_lo = reinterpret_cast<_Float16*>(take((size_t)g.V * g.E * 2));
+    const size_t RB = rowsP / 32;
+    c.hfrag[0] = reinterpret_cast<f32x4*>(take(RB * g.KBh * 128 * 16));
+    c.hfrag[1] = reinterpret_cast<f32x4*>(take(RB * g.KBh * 128 * 16));
+    c.cfrag = reinterpret_cast<f32x4*>(take(RB * (g.H / 8) * 64 * 16));
+    c.rec = reinterpret_cast<float2*>(take((size_t)g.MBp * 2 * rowsP * sizeof(float2)));
+    c.tok = reinterpret_cast<int*>(take(rowsP * sizeof(int)));
+    c.bytes = o;
+    return c;
+}
+
+size_t pad128(size_t r) { return (r + 127) / 128 * 128; }
+
+// ------------------------------------------------------------------ per-call weight preparation
+__global__ __launch_bounds__(256) void k_genw_absmax(const float* x, size_t n, unsigned* out) {
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    __shared__ unsigned red[4];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m) atomicMax(out, m);
+    }
+}
+
+// exponent e with m * 2^e in [2^13, 2^14) (0 for m = 0 / inf / nan)
+__device__ __forceinline__ int scale_exp(float m) {
+    if (!(m > 0.f) || m == __builtin_inff()) return 0;
+    int ex = 0;
+    (void)frexpf(m, &ex);
+    return 14 - ex;
+}
+
+// absmax[0..3] = |max| bits of W_out, W_ih, W_hh, emb.  Publishes the power-of-two scales (the two products of the
+// cell, W_ih.x and W_hh.h, share one accumulator and therefore one combined scale) and the fp32 side operands:
+// bias2[v] = b_out[v]*log2(e) (TG_NEG_BIG past the vocabulary's end), gb = b_ih + b_hh.
+__global__ __launch_bounds__(256) void k_genw_prep(const unsigned* absmax, Scales* sc, const float* b_out, int V, int Vp,
+                                                   float* bias2, const float* b_ih, const float* b_hh, int H4, float* gb) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        const int eW = scale_exp(__uint_as_float(absmax[0]) * kL2E);
+        const int eI = scale_exp(__uint_as_float(absmax[1]));
+        const int eHH = scale_exp(__uint_as_float(absmax[2]));
+        const int eX = scale_exp(__uint_as_float(absmax[3]));
+        const int e = (eI + eX < eHH + 13) ? eI + eX : eHH + 13;
+        Scales s;
+        s.sWout = ldexpf(1.f, eW);
+        s.invProj = ldexpf(1.f, -(eW + 13));
+        s.sX = ldexpf(1.f, eX);
+        s.sI = ldexpf(1.f, e - eX);
+        s.sHH = ldexpf(1.f, e - 13);
+        s.invCell = ldexpf(1.f, -e);
+        *sc = s;
+    }
+    if (i < Vp) bias2[i] = i < V ? b_out[i] * kL2E : TG_NEG_BIG;
+    if (i < H4) gb[i] = b_ih[i] + b_hh[i];
+}
+
+__device__ __forceinline__ void split8(const float (&x)[8], f32x4& hi, f32x4& lo) {
+    f16x8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 xh = (_Float16)x[j];
+        h[j] = xh;
+        l[j] = (_Float16)(x[j] - (float)xh);
+    }
+    hi = __builtin_bit_cast(f32x4, h);
+    lo = __builtin_bit_cast(f32x4, l);
+}
+
+// A fragments.  Piece ((mb*KB + kb)*2 + part)*64 + lane: lane (am, kh) holds the 8 halves k = 16kb + 8kh + 0..7 of
+// tile row am, part 0 = fp16 hi, 1 = residual.  Tile row am of block mb is
+//   PROJ: vocab entry 32mb + 16((am>>2)&1) + (am&3) + 4(am>>3)   -> D reg r of lane (n, hh) is entry 32mb + 16hh + r:
+//         16 consecutive entries (one sampler tile) per lane;   values W_out*log2(e)*sWout
+//   CELL: gate row (am>>3)*H + 8mb + (am&7)                       -> D reg r of lane (n, hh) is gate r>>2 of hidden unit
+//         8mb + 4hh + (r&3): i,f,g,o of a unit in one lane;      values W_ih*sI (k < E) | W_hh*sHH
+template <bool PROJ>
+__global__ __launch_bounds__(64) void k_genw_make_a(const float* __restrict__ w0, const float* __restrict__ w1, int V, int E,
+                                                    int H, int KB, const Scales* sc, f32x4* __restrict__ dst) {
+    const int kb = blockIdx.x, mb = blockIdx.y, lane = threadIdx.x;
+    const int am = lane & 31, kh = lane >> 5;
+    const int k = 16 * kb + 8 * kh;
+    float x[8];
+    if constexpr (PROJ) {
+        const int v = 32 * mb + 16 * ((am >> 2) & 1) + (am & 3) + 4 * (am >> 3);
+        const float s = sc->sWout;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = v < V ? (w0[(size_t)v * H + k + j] * kL2E) * s : 0.f;
+    } else {
+        const int grow = (am >> 3) * H + 8 * mb + (am & 7);
+        const bool xpart = k < E;
+        const float* src = xpart ? w0 + (size_t)grow * E + k : w1 + (size_t)grow * H + (k - E);
+        const float s = xpart ? sc->sI : sc->sHH;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = src[j] * s;
+    }
+    f32x4 hi, lo;
+    split8(x, hi, lo);
+    f32x4* d = dst + ((size_t)(mb * KB + kb) * 2) * 64 + lane;
+    d[0] = hi;
+    d[64] = lo;
+}
+
+// embedding table -> fp16 hi / residual, row-major [V][E], scaled by sX
+__global__ __launch_bounds__(256) void k_genw_split_emb(const float* __restrict__ emb, size_t n8, const Scales* sc,
+                                                        f32x4* __restrict__ hi, f32x4* __restrict__ lo) {
+    const float s = sc->sX;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(emb)[2 * i], b = reinterpret_cast<const f32x4*>(emb)[2 * i + 1];
+        const float x[8] = {a[0] * s, a[1] * s, a[2] * s, a[3] * s, b[0] * s, b[1] * s, b[2] * s, b[3] * s};
+        f32x4 h, l;
+        split8(x, h, l);
+        hi[i] = h;
+        lo[i] = l;
+    }
+}
+
+// ------------------------------------------------------------------ state layouts
+// hfrag: B fragments of h*2^13.  Piece ((rb*KBh + kb)*2 + part)*64 + lane, lane (j, kh): row 32rb + j, k = 16kb + 8kh + 0..7.
+// cfrag: piece (rb*(H/8) + T)*64 + lane, lane (j, hh): c of units 8T + 4hh + 0..3 of row 32rb + j (the cell epilogue's
+//        own accumulator layout; nothing else reads it).
+__device__ __forceinline__ void store_h4(f32x4* hfrag, int KBh, int row, int T, int hh, const f32x4& h) {
+    const int rb = row >> 5, j = row & 31, kb = T >> 1, kh = T & 1;
+    const size_t piece = ((size_t)(rb * KBh + kb) * 2) * 64 + kh * 32 + j;
+    f16x4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = h[e] * kHScale;
+        const _Float16 xh = (_Float16)x;
+        hi[e] = xh;
+        lo[e] = (_Float16)(x - (float)xh);
+    }
+    char* p = reinterpret_cast<char*>(hfrag);
+    *reinterpret_cast<f16x4*>(p + piece * 16 + 8 * hh) = hi;
+    *reinterpret_cast<f16x4*>(p + (piece + 64) * 16 + 8 * hh) = lo;
+}
+
+// rows [r0, r1) take the state after their prefix (tg_gen_teacher_forced's states_out for that step: [B][2][H]);
+// row r0 + k belongs to sentence k % B.  src == nullptr: zero state (free-running sample).
+__global__ __launch_bounds__(256) void k_genw_enter(const float* __restrict__ src, int B, int H, int KBh, int r0, int r1,
+                                                    f32x4* hfrag, f32x4* cfrag) {
+    const int q = H >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)(r1 - r0) * q) return;
+    const int k = (int)(idx / q), uq = (int)(idx - (size_t)k * q);
+    const int row = r0 + k, T = uq >> 1, hh = uq & 1;
+    f32x4 h = {0.f, 0.f, 0.f, 0.f}, c = h;
+    if (src) {
+        const float* s = src + (size_t)(k % B) * 2 * H + 4 * uq;
+        h = *reinterpret_cast<const f32x4*>(s);
+        c = *reinterpret_cast<const f32x4*>(s + H);
+    }
+    store_h4(hfrag, KBh, row, T, hh, h);
+    cfrag[((size_t)(row >> 5) * (H >> 3) + T) * 64 + hh * 32 + (row & 31)] = c;
+}
+
+// ------------------------------------------------------------------ the GEMM
+struct GemmArgs {
+    const f32x4* A;   // fragments [MB][KB][2][64]
+    int KB, MT, RT;   // k blocks, 128-row M tiles, 128-row N (completion) tiles
+    const f32x4* Bh;  // hfrag (PROJ: the whole B operand; CELL: k blocks KBe..)
+    int KBh, KBe;
+    const _Float16* emb_hi; const _Float16* emb_lo; const int* tok; int E, V;  // CELL: x = emb[tok], gathered
+    const Scales* sc;
+    const float* bias2; float2* rec; size_t rowsP;  // PROJ epilogue
+    const float* gb; f32x4* cfrag; f32x4* hdst; int H;  // CELL epilogue
+};
+
+template <bool PROJ>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_genw_gemm(const GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [2 buffers][A 1024 | B 1024] pieces = 64 KiB
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wm = w >> 1, wn = w & 1;
+    // XCD-aware order: the workgroups that share an XCD (id % 8) walk consecutive logical ids; 8 consecutive ids
+    // share one A tile, and one group of 8 row tiles stays put while the M tiles sweep (its B stays in that L2)
+    const int nb = gridDim.x;
+    const int lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+    const int per = 8 * a.MT;
+    const int rtg = lb / per, rem = lb - rtg * per;
+    const int mt = rem >> 3, rt = rtg * 8 + (rem & 7);
+    if (rt >= a.RT) return;
+    const int mb0 = 4 * mt, rb0 = 4 * rt;
+    const int S = a.KB >> 1;
+    const int Se = PROJ ? 0 : (a.KBe >> 1);
+
+    int tokr[4] = {0, 0, 0, 0};
+    if constexpr (!PROJ) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tokr[i] = tg_min(tg_max(a.tok[(rb0 + i) * 32 + (tid & 31)], 0), a.V - 1);
+    }
+    f32x4 pa[4], pb[4];
+    auto load_stage = [&](int s) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pa[i] = a.A[((size_t)(mb0 + i) * a.KB + 2 * s) * 128 + tid];
+        if (PROJ || s >= Se) {
+            const int sh = s - Se;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb[i] = a.Bh[((size_t)(rb0 + i) * a.KBh + 2 * sh) * 128 + tid];
+        } else {
+            const _Float16* tab = ((tid >> 6) & 1) ? a.emb_lo : a.emb_hi;
+            const int k = (2 * s + (tid >> 7)) * 16 + 8 * ((tid >> 5) & 1);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pb[i] = *reinterpret_cast<const f32x4*>(tab + (size_t)tokr[i] * a.E + k);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        f32x4* d = lds + buf * 2048 + tid;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { d[i * 256] = pa[i]; d[1024 + i * 256] = pb[i]; }
+    };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+    for (int s = 0; s < S; ++s) {
+        if (s + 1 < S) load_stage(s + 1);
+        const f32x4* la = lds + (s & 1) * 2048 + (2 * wm) * 256 + lane;
+        const f32x4* lbp = lds + (s & 1) * 2048 + 1024 + (2 * wn) * 256 + lane;
+#pragma unroll
+        for (int kbl = 0; kbl < 2; ++kbl) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128]);
+                al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
+                bh[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128]);
+                bl[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128 + 64]);
+            }
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    acc[mi][ni] = TG_MFMA16(al[mi], bh[ni], acc[mi][ni]);
+                    acc[mi][ni] = TG_MFMA16(ah[mi], bl[ni], acc[mi][ni]);
+                    acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
+                }
+        }
+        if (s + 1 < S) store_stage((s + 1) & 1);
+        __syncthreads();
+    }
+
+    if constexpr (PROJ) {
+        // per (row, 16-entry tile): m = max logit (base 2), s = sum 2^(l - m) in entry order
+        const float inv = a.sc->invProj;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int mb = mb0 + 2 * wm + mi;
+            float bias[16];
+            const f32x4* pbias = reinterpret_cast<const f32x4*>(a.bias2 + 32 * mb + 16 * hh);
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 b4 = pbias[q4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias[4 * q4 + e] = b4[e];
+            }
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int row = (rb0 + 2 * wn + ni) * 32 + n;
+                float l[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) l[r] = __builtin_fmaf(acc[mi][ni][r], inv, bias[r]);
+                float m = l[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, l[r]);
+                float ev[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(l[r] - m);
+                float s = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s += ev[r];
+                a.rec[(size_t)(2 * mb + hh) * a.rowsP + row] = make_float2(m, s);
+            }
+        }
+    } else {
+        const float inv = a.sc->invCell;
+        const int H = a.H;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            const int T = mb0 + 2 * wm + mi;
+            const int u0 = 8 * T + 4 * hh;
+            f32x4 gbias[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gbias[q] = *reinterpret_cast<const f32x4*>(a.gb + q * H + u0);
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int rb = rb0 + 2 * wn + ni;
+                f32x4* cp = a.cfrag + ((size_t)rb * (H >> 3) + T) * 64 + lane;
+                const f32x4 c_old = *cp;
+                f32x4 c_new, h_new;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float ig = tg_sigmoid(__builtin_fmaf(acc[mi][ni][e], inv, gbias[0][e]));
+                    const float fg = tg_sigmoid(__builtin_fmaf(acc[mi][ni][4 + e], inv, gbias[1][e]));
+                    const float gg = tg_tanh(__builtin_fmaf(acc[mi][ni][8 + e], inv, gbias[2][e]));
+                    const float og = tg_sigmoid(__builtin_fmaf(acc[mi][ni][12 + e], inv, gbias[3][e]));
+                    const float cn = fg * c_old[e] + ig * gg;
+                    c_new[e] = cn;
+                    h_new[e] = og * tg_tanh(cn);
+                }
+                *cp = c_new;
+                store_h4(a.hdst, a.KBh, rb * 32 + n, T, hh, h_new);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ row <-> output mapping
+struct RowMap {
+    int rollout;        // 1: rows are (given_num, rollout index, sentence) of tg_gen_rollout; 0: tg_gen_sample rows
+    int B, L, nI, g_lo, i_lo;
+    int N, n0;          // sample: total rows, first row of the chunk
+};
+__device__ __forceinline__ void map_row(const RowMap& m, int row, int t, size_t& orow, size_t& uidx) {
+    if (m.rollout) {
+        const int nIB = m.nI * m.B;
+        const int gi = row / nIB, rem = row - gi * nIB, il = rem / m.B, b = rem - il * m.B;
+        const size_t ig = (size_t)(m.i_lo + il) * m.L + (m.g_lo + gi - 1);
+        orow = ig * m.B + b;
+        uidx = (ig * m.L + t) * m.B + b;
+    } else {
+        orow = (size_t)m.n0 + row;
+        uidx = (size_t)t * m.N + orow;
+    }
+}
+
+// out[i, g-1, b, :g] = sentences[b, :g] for every (i, g, b) of the chunk, g = L included (utils/rollout.py:42)
+__global__ __launch_bounds__(256) void k_genw_prefix(const int64_t* __restrict__ sentences, int64_t* __restrict__ out, int B,
+                                                     int L, int nI, int i_lo, int g_lo, int nG) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)nG * nI * B * L;
+    if (idx >= total) return;
+    const int s = (int)(idx % L);
+    const size_t r = idx / L;
+    const int b = (int)(r % B);
+    const size_t r2 = r / B;
+    const int il = (int)(r2 % nI), gi = (int)(r2 / nI);
+    const int g = g_lo + gi;
+    if (s < g) out[(((size_t)(i_lo + il) * L + (g - 1)) * B + b) * L + s] = sentences[(size_t)b * L + s];
+}
+
+// ------------------------------------------------------------------ canonical draw from the tile records
+struct DrawArgs {
+    Geom g;
+    RowMap map;
+    const float2* rec; size_t rowsP;
+    int A, t;                    // active rows, position being drawn
+    const float* uniforms; const int64_t* forced; int64_t* out; int* tok;
+    const f32x4* hfrag; const float* w_out; const float* bias2;
+};
+
+// 64 rows per workgroup; wave = span, lane = row for the scans; 8 consecutive lanes per row for the recompute.
+// Same decisions as oracle canonical_draw: tile sums (fp32, entry order) -> group sums (fp32, tile order) -> span
+// sums / total / target / every prefix comparison in fp64.  Tile sums come from the records at their own maximum and
+// are moved to the group's maximum in fp32, the group sums to the row's maximum in fp64.
+__global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
+    __shared__ float mbuf[8][64];
+    __shared__ double sbuf[8][64];
+    __shared__ int selT[64];
+    __shared__ double selp[64], tgt[64];
+    __shared__ float Mrow[64];
+    __shared__ float wbuf[64][17];
+    const int tid = threadIdx.x, sp = tid >> 6, ln = tid & 63;
+    const int row = blockIdx.x * 64 + ln;
+    const bool valid = row < a.A;
+    const int rowc = valid ? row : a.A - 1;
+    const int NT = a.g.NT, GK = a.g.GK, V = a.g.V;
+    const int ntv = tg_min(tg_max(a.g.NT16 - sp * NT, 0), NT);  // tiles of this span that hold vocabulary
+    const int ngv = (ntv + GK - 1) / GK;
+    const size_t rs = a.rowsP;
+    const float2* rp = a.rec + (size_t)(sp * NT) * rs + rowc;
+
+    auto load_group = [&](int gq, float2 (&r)[8]) {
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) {
+            const int q = gq * GK + tt;
+            r[tt] = make_float2(TG_NEG_BIG, 0.f);
+            if (tt < GK && q < ntv) r[tt] = rp[(size_t)q * rs];
+        }
+    };
+    auto group_max = [&](const float2 (&r)[8]) {
+        float m = r[0].x;
+#pragma unroll
+        for (int tt = 1; tt < 8; ++tt) m = __builtin_fmaxf(m, r[tt].x);
+        return m;
+    };
+    float mg[kMaxNG], cg[kMaxNG];
+    float ms = TG_NEG_BIG;
+#pragma unroll
+    for (int gq = 0; gq < kMaxNG; ++gq) {
+        mg[gq] = TG_NEG_BIG;
+        cg[gq] = 0.f;
+        if (gq < ngv) {
+            float2 r[8];
+            load_group(gq, r);
+            const float m = group_max(r);
+            float c = 0.f;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) c += r[tt].y * __builtin_amdgcn_exp2f(r[tt].x - m);
+            mg[gq] = m;
+            cg[gq] = c;
+            ms = __builtin_fmaxf(ms, m);
+        }
+    }
+    mbuf[sp][ln] = ms;
+    __syncthreads();
+    float M = mbuf[0][ln];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) M = __builtin_fmaxf(M, mbuf[s][ln]);
+    double cq[kMaxNG];
+    double ssum = 0.0;
+#pragma unroll
+    for (int gq = 0; gq < kMaxNG; ++gq) {
+        cq[gq] = 0.0;
+        if (gq < ngv) {
+            cq[gq] = (double)cg[gq] * exp2((double)mg[gq] - (double)M);
+            ssum += cq[gq];
+        }
+    }
+    sbuf[sp][ln] = ssum;
+    __syncthreads();
+    {
+        double S = 0.0;
+#pragma unroll
+        for (int s = 0; s < 8; ++s) S += sbuf[s][ln];
+        size_t orow, uidx;
+        map_row(a.map, rowc, a.t, orow, uidx);
+        const double target = (double)a.uniforms[uidx] * S;
+        const int last_span = (V - 1) / a.g.Ls;
+        int sel = last_span;
+        double p = 0.0;
+        for (int s = 0; s < 8; ++s) {
+            const double ss = sbuf[s][ln];
+            if (p + ss > target || s == last_span) { sel = s; break; }
+            p += ss;
+        }
+        if (sel == sp) {
+            int gsel = ngv - 1;
+            bool found = false;
+#pragma unroll
+            for (int gq = 0; gq < kMaxNG; ++gq) {
+                if (gq < ngv && !found) {
+                    if (p + cq[gq] > target || gq == ngv - 1) { gsel = gq; found = true; }
+                    else p += cq[gq];
+                }
+            }
+            float2 r[8];
+            load_group(gsel, r);
+            const float m = group_max(r);  // the same value as mg[gsel]
+            const double fac = exp2((double)m - (double)M);
+            const int ntg = tg_min(GK, ntv - gsel * GK);
+            int tsel = ntg - 1;
+            found = false;
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                if (tt < ntg && !found) {
+                    const double ts = (double)(r[tt].y * __builtin_amdgcn_exp2f(r[tt].x - m)) * fac;
+                    if (p + ts > target || tt == ntg - 1) { tsel = tt; found = true; }
+                    else p += ts;
+                }
+            }
+            selT[ln] = sp * NT + gsel * GK + tsel;
+            selp[ln] = p;
+            tgt[ln] = target;
+            Mrow[ln] = M;
+        }
+    }
+    __syncthreads();
+    // the chosen tile's 16 logits again, fp32: thread (row, c) takes the 16-B column slices c, c+8, .. of every weight
+    // row (the 8 threads of a row read each 128 B of it as one line) against h = (hi + lo) / 2^13, the very operand
+    // of the first pass; partial dots summed across the 8 lanes
+    {
+        const int rr = tid >> 3, c = tid & 7;
+        const int rrow = tg_min(blockIdx.x * 64 + rr, a.A - 1);
+        const int v0 = selT[rr] * 16;
+        const float Mr = Mrow[rr];
+        const int H = a.g.H, KBh = a.g.KBh;
+        const int rb = rrow >> 5, j = rrow & 31;
+        const char* hb = reinterpret_cast<const char*>(a.hfrag);
+        auto dpp_add = [](float x, auto ctrl) {
+            constexpr int C = decltype(ctrl)::value;
+            const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, 0xf, 0xf, true);
+            return x + __builtin_bit_cast(float, y);
+        };
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float part[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) part[i] = 0.f;
+            for (int ks = 0; ks < (H >> 5); ++ks) {
+                const int k0 = 32 * ks + 4 * c;
+                const size_t piece = ((size_t)(rb * KBh + (k0 >> 4)) * 2) * 64 + ((k0 >> 3) & 1) * 32 + j;
+                const f16x4 hi = *reinterpret_cast<const f16x4*>(hb + piece * 16 + 2 * (k0 & 7));
+                const f16x4 lo = *reinterpret_cast<const f16x4*>(hb + (piece + 64) * 16 + 2 * (k0 & 7));
+                float h4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) h4[e] = ((float)hi[e] + (float)lo[e]) * (1.f / kHScale);
+                f32x4 wv[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    wv[i] = *reinterpret_cast<const f32x4*>(a.w_out + (size_t)tg_min(v0 + 8 * half + i, V - 1) * H + k0);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    float p = part[i];
+                    p = __builtin_fmaf(wv[i][0], h4[0], p);
+                    p = __builtin_fmaf(wv[i][1], h4[1], p);
+                    p = __builtin_fmaf(wv[i][2], h4[2], p);
+                    p = __builtin_fmaf(wv[i][3], h4[3], p);
+                    part[i] = p;
+                }
+            }
+            float mine = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                float p = part[i];
+                p = dpp_add(p, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+                p = dpp_add(p, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+                p = dpp_add(p, std::integral_constant<int, 0x141>{});  // row_half_mirror
+                mine = (i == c) ? p : mine;
+            }
+            const int e = 8 * half + c;
+            const int v = v0 + e;
+            float wgt = 0.f;
+            if (v < V) wgt = __builtin_amdgcn_exp2f(__builtin_fmaf(mine, kL2E, a.bias2[v]) - Mr);
+            wbuf[rr][e] = wgt;
+        }
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int v0 = selT[ln] * 16;
+        const int t_hi = tg_min(V, v0 + 16);
+        const double target = tgt[ln];
+        const double p = selp[ln];
+        int drawn = t_hi - 1;
+        float pp = 0.f;
+        bool hit = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            pp += wbuf[ln][r];
+            if (!hit && v0 + r < t_hi && p + (double)pp > target) { drawn = v0 + r; hit = true; }
+        }
+        if (valid) {
+            size_t orow, uidx;
+            map_row(a.map, row, a.t, orow, uidx);
+            a.out[orow * a.map.L + a.t] = drawn;
+            int nt = drawn;
+            if (a.forced) nt = tg_min(tg_max((int)a.forced[orow * a.map.L + a.t], 0), V - 1);
+            a.tok[row] = nt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_genw_fill_tok(int* tok, size_t n, int v) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) tok[i] = v;
+}
+
+// ------------------------------------------------------------------ host side
+#define GW_CHECK_LAUNCH(what)                                              \
+    do {                                                                   \
+        hipError_t e_ = hipGetLastError();                                 \
+        if (e_ != hipSuccess) {                                            \
+            tg_set_error("%s launch: %s", what, hipGetErrorString(e_));    \
+            return TG_ERR_LAUNCH;                                          \
+        }                                                                  \
+    } while (0)
+
+int ensure_lds() {
+    static thread_local bool done = false;
+    if (done) return TG_OK;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<true>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    if (e != hipSuccess) {
+        tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    done = true;
+    return TG_OK;
+}
+
+int prep_weights(const TgGenWeights& w, const Geom& g, const Carve& c, hipStream_t st) {
+    if (hipMemsetAsync(c.absmax, 0, 64, st) != hipSuccess) {
+        tg_set_error("hipMemsetAsync failed");
+        return TG_ERR_LAUNCH;
+    }
+    auto amax = [&](const float* x, size_t n, int slot) {
+        const size_t blocks = (n + 1023) / 1024;
+        hipLaunchKernelGGL(k_genw_absmax, dim3((unsigned)(blocks < 1024 ? blocks : 1024)), dim3(256), 0, st, x, n,
+                           c.absmax + slot);
+    };
+    amax(w.w_out, (size_t)g.V * g.H, 0);
+    amax(w.w_ih, (size_t)4 * g.H * g.E, 1);
+    amax(w.w_hh, (size_t)4 * g.H * g.H, 2);
+    amax(w.emb, (size_t)g.V * g.E, 3);
+    const int Vp = g.MBp * 32, H4 = 4 * g.H;
+    const int nmax = Vp > H4 ? Vp : H4;
+    hipLaunchKernelGGL(k_genw_prep, dim3((nmax + 255) / 256), dim3(256), 0, st, c.absmax, c.sc, w.b_out, g.V, Vp, c.bias2,
+                       w.b_ih, w.b_hh, H4, c.gb);
+    hipLaunchKernelGGL(k_genw_make_a<true>, dim3(g.KBh, g.MBp), dim3(64), 0, st, w.w_out, (const float*)nullptr, g.V, g.E,
+                       g.H, g.KBh, c.sc, c.a_proj);
+    hipLaunchKernelGGL(k_genw_make_a<false>, dim3(g.KBc, 4 * g.H / 32), dim3(64), 0, st, w.w_ih, w.w_hh, g.V, g.E, g.H,
+                       g.KBc, c.sc, c.a_cell);
+    const size_t n8 = (size_t)g.V * g.E / 8;
+    const size_t blocks = (n8 + 255) / 256;
+    hipLaunchKernelGGL(k_genw_split_emb, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, w.emb, n8, c.sc,
+                       reinterpret_cast<f32x4*>(c.emb_hi), reinterpret_cast<f32x4*>(c.emb_lo));
+    GW_CHECK_LAUNCH("k_genw weight preparation");
+    return TG_OK;
+}
+
+void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
+                 int hdst, hipStream_t st) {
+    GemmArgs a = {};
+    a.RT = (rows + 127) / 128;
+    a.KBh = g.KBh;
+    a.KBe = g.KBe;
+    a.sc = c.sc;
+    a.H = g.H;
+    a.E = g.E;
+    a.V = g.V;
+    const int rtg = (a.RT + 7) / 8;
+    if (proj) {
+        a.A = c.a_proj;
+        a.KB = g.KBh;
+        a.MT = g.MBp / 4;
+        a.Bh = c.hfrag[hsrc];
+        a.bias2 = c.bias2;
+        a.rec = c.rec;
+        a.rowsP = rowsP;
+        tg_prof_begin(TG_KERNEL_GENW_PROJ, st);
+        hipLaunchKernelGGL(k_genw_gemm<true>, dim3(rtg * 8 * a.MT), dim3(256), 65536, st, a);
+        tg_prof_end(st);
+    } else {
+        a.A = c.a_cell;
+        a.KB = g.KBc;
+        a.MT = 4 * g.H / 128;
+        a.Bh = c.hfrag[hsrc];
+        a.emb_hi = c.emb_hi;
+        a.emb_lo = c.emb_lo;
+        a.tok = c.tok;
+        a.gb = c.gb;
+        a.cfrag = c.cfrag;
+        a.hdst = c.hfrag[hdst];
+        tg_prof_begin(TG_KERNEL_GENW_CELL, st);
+        hipLaunchKernelGGL(k_genw_gemm<false>, dim3(rtg * 8 * a.MT), dim3(256), 65536, st, a);
+        tg_prof_end(st);
+    }
+}
+
+void launch_draw(const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, const RowMap& map, int rows, int t,
+                 int hsrc, const float* uniforms, const int64_t* forced, int64_t* out, hipStream_t st) {
+    DrawArgs d = {};
+    d.g = g;
+    d.map = map;
+    d.rec = c.rec;
+    d.rowsP = rowsP;
+    d.A = rows;
+    d.t = t;
+    d.uniforms = uniforms;
+    d.forced = forced;
+    d.out = out;
+    d.tok = c.tok;
+    d.hfrag = c.hfrag[hsrc];
+    d.w_out = w.w_out;
+    d.bias2 = c.bias2;
+    tg_prof_begin(TG_KERNEL_GENW_DRAW, st);
+    hipLaunchKernelGGL(k_genw_draw, dim3((rows + 63) / 64), dim3(512), 0, st, d);
+    tg_prof_end(st);
+}
+
+int check_shape(const TgGenWeights& w, const Geom& g) {
+    if (w.H % 32 || w.E % 32 || g.NG > kMaxNG) {
+        tg_set_error("wide generator path: needs E, H multiples of 32 and V <= 32768 (V=%d E=%d H=%d)", w.V, w.E, w.H);
+        return TG_ERR_ARG;
+    }
+    return TG_OK;
+}
+
+}  // namespace
+
+bool tg_genw_applies(const TgGenWeights* w) {
+    return w->precision == TG_GEN_SPLIT_F16 && !(w->E == 32 && w->H == 32) && w->H % 32 == 0 && w->E % 32 == 0 &&
+           make_geom(*w).NG <= kMaxNG;
+}
+
+static size_t chunk_rows_rollout(int B, int L, int n_i, int* nIc_out) {
+    const size_t per_i = (size_t)B * L;
+    size_t nIc = kChunkRows / per_i;
+    if (nIc < 1) nIc = 1;
+    if ((size_t)n_i < nIc) nIc = n_i > 0 ? n_i : 1;
+    if (nIc_out) *nIc_out = (int)nIc;
+    return pad128(nIc * per_i);
+}
+
+size_t tg_genw_rollout_workspace_bytes(const TgGenWeights* w, int B, int L, int n_i) {
+    const Geom g = make_geom(*w);
+    return carve(g, chunk_rows_rollout(B, L, n_i, nullptr), nullptr).bytes;
+}
+
+size_t tg_genw_sample_workspace_bytes(const TgGenWeights* w, int N) {
+    const Geom g = make_geom(*w);
+    const size_t rows = (size_t)N < (size_t)kChunkRows ? (size_t)(N > 0 ? N : 1) : (size_t)kChunkRows;
+    return carve(g, pad128(rows), nullptr).bytes;
+}
+
+int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int L, int g_lo, int g_hi, int i_lo, int i_hi,
+                    const float* uniforms, const int64_t* forced, int64_t* completions, const float* states,
+                    void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const Geom g = make_geom(*w);
+    int rc = check_shape(*w, g);
+    if (rc) return rc;
+    int nIc = 1;
+    const size_t rowsP = chunk_rows_rollout(B, L, i_hi - i_lo, &nIc);
+    const Carve c = carve(g, rowsP, workspace);
+    if (!workspace || workspace_bytes < c.bytes) {
+        tg_set_error("wide generator path: workspace too small (%zu < %zu)", workspace_bytes, c.bytes);
+        return TG_ERR_WORKSPACE;
+    }
+    if ((rc = ensure_lds())) return rc;
+    if ((rc = prep_weights(*w, g, c, st))) return rc;
+    const int g_hs = g_hi < L - 1 ? g_hi : L - 1;  // given_num = L only copies
+    for (int ic = i_lo; ic < i_hi; ic += nIc) {
+        const int nI = (i_hi - ic) < nIc ? (i_hi - ic) : nIc;
+        const int nIB = nI * B;
+        {
+            const int nG = g_hi - g_lo + 1;
+            const size_t total = (size_t)nG * nIB * L;
+            hipLaunchKernelGGL(k_genw_prefix, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, sentences,
+                               completions, B, L, nI, ic, g_lo, nG);
+        }
+        if (g_hs < g_lo) continue;
+        RowMap map = {};
+        map.rollout = 1;
+        map.B = B;
+        map.L = L;
+        map.nI = nI;
+        map.g_lo = g_lo;
+        map.i_lo = ic;
+        if (hipMemsetAsync(c.tok, 0, rowsP * sizeof(int), st) != hipSuccess) {
+            tg_set_error("hipMemsetAsync failed");
+            return TG_ERR_LAUNCH;
+        }
+        int p = 0;
+        for (int t = g_lo; t < L; ++t) {
+            const int a_prev = t - 1 >= g_lo ? ((t - 1 < g_hs ? t - 1 : g_hs) - g_lo + 1) * nIB : 0;
+            const int a_t = ((t < g_hs ? t : g_hs) - g_lo + 1) * nIB;
+            // rows that drew position t-1 take a cell step on that token; rows with given_num == t enter with the
+            // state after their t prefix tokens (utils/rollout.py:35-38)
+            if (a_prev > 0) launch_gemm(false, *w, g, c, rowsP, a_prev, p, 1 - p, st);
+            if (t <= g_hs) {
+                const size_t n = (size_t)(a_t - a_prev) * (g.H / 4);
+                hipLaunchKernelGGL(k_genw_enter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
+                                   states + (size_t)t * B * 2 * g.H, B, g.H, g.KBh, a_prev, a_t, c.hfrag[1 - p], c.cfrag);
+            }
+            launch_gemm(true, *w, g, c, rowsP, a_t, 1 - p, 0, st);
+            launch_draw(*w, g, c, rowsP, map, a_t, t, 1 - p, uniforms, forced, completions, st);
+            p = 1 - p;
+        }
+        GW_CHECK_LAUNCH("k_genw rollout step");
+    }
+    GW_CHECK_LAUNCH("k_genw rollout");
+    return TG_OK;
+}
+
+int tg_genw_sample(const TgGenWeights* w, int N, int L, int64_t start_letter, const float* uniforms,
+                   const int64_t* forced, int64_t* out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const Geom g = make_geom(*w);
+    int rc = check_shape(*w, g);
+    if (rc) return rc;
+    const size_t rows_c = (size_t)N < (size_t)kChunkRows ? (size_t)N : (size_t)kChunkRows;
+    const size_t rowsP = pad128(rows_c);
+    const Carve c = carve(g, rowsP, workspace);
+    if (!workspace || workspace_bytes < c.bytes) {
+        tg_set_error("wide generator path: workspace too small (%zu < %zu)", workspace_bytes, c.bytes);
+        return TG_ERR_WORKSPACE;
+    }
+    if ((rc = ensure_lds())) return rc;
+    if ((rc = prep_weights(*w, g, c, st))) return rc;
+    for (size_t n0 = 0; n0 < (size_t)N; n0 += rows_c) {
+        const int rows = (int)(((size_t)N - n0) < rows_c ? ((size_t)N - n0) : rows_c);
+        RowMap map = {};
+        map.rollout = 0;
+        map.L = L;
+        map.N = N;
+        map.n0 = (int)n0;
+        hipLaunchKernelGGL(k_genw_fill_tok, dim3((unsigned)((rowsP + 255) / 256)), dim3(256), 0, st, c.tok, rowsP,
+                           (int)start_letter);
+        {   // zero state (models/generator.py:102-109)
+            const size_t n = (size_t)rows * (g.H / 4);
+            hipLaunchKernelGGL(k_genw_enter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)nullptr, 1,
+                               g.H, g.KBh, 0, rows, c.hfrag[0], c.cfrag);
+        }
+        int p = 0;
+        for (int t = 0; t < L; ++t) {
+            launch_gemm(false, *w, g, c, rowsP, rows, p, 1 - p, st);
+            launch_gemm(true, *w, g, c, rowsP, rows, 1 - p, 0, st);
+            launch_draw(*w, g, c, rowsP, map, rows, t, 1 - p, uniforms, forced, out, st);
+            p = 1 - p;
+        }
+        GW_CHECK_LAUNCH("k_genw sample step");
+    }
+    return TG_OK;
+}

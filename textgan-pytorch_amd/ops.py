@@ -106,7 +106,7 @@ def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_l
         raise RuntimeError("textgan_hip: uniforms must have R*L*L*B = %d elements, got %d"
                            % (R * L * L * B, uniforms.numel()))
     comp = out if out is not None else torch.empty(R, L, B, L, dtype=I64, device=s.device)
-    nbytes = _lib.lib().tg_gen_rollout_workspace_bytes(C.byref(w), B, L)
+    nbytes = _lib.lib().tg_gen_rollout_workspace_bytes(C.byref(w), B, L, i_hi - i_lo)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
     f = None if forced is None else _tokens(forced, "forced")[0]
     _lib.check(_lib.lib().tg_gen_rollout(
@@ -124,7 +124,7 @@ def gen_sample(gen, N, L, start_letter, uniforms, forced=None, precision=None):
         raise RuntimeError("textgan_hip: uniforms must have L*N = %d elements" % (L * N))
     out = torch.empty(N, L, dtype=I64, device=uniforms.device)
     f = None if forced is None else _tokens(forced, "forced")[0]
-    nbytes = _lib.lib().tg_gen_sample_workspace_bytes(C.byref(w))
+    nbytes = _lib.lib().tg_gen_sample_workspace_bytes(C.byref(w), N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=uniforms.device) if nbytes else None
     _lib.check(_lib.lib().tg_gen_sample(C.byref(w), N, L, int(start_letter), _lib.dev_ptr(uniforms, F32, "uniforms"),
                                         _lib.dev_ptr(f, I64, "forced"), _lib.dev_ptr(out), _lib.dev_ptr(ws), nbytes,
