@@ -15,6 +15,8 @@
 // tg_dis.hip.  Every operand is kept in HBM in MFMA fragment order ("piece" = the 16 B one lane feeds to
 // one MFMA), so staging is a linear copy and every LDS read is a conflict-free 1-KiB row.
 // Replaces models/generator.py:40-84 and utils/rollout.py:25-55 of the reference for those shapes.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "tg_common.h"
@@ -39,7 +41,7 @@ struct Scales {  // device side, written by k_genw_prep
 struct Geom {
     int V, E, H;
     int KBh, KBe, KBc;    // 16-wide k blocks of H, E, E+H
-    int MBp;              // 32-entry vocab blocks, padded to whole 128-entry tiles
+    int MBp;              // 32-entry vocab blocks, padded to whole 256-entry tiles
     int NT16;             // ceil(V/16): 16-entry tiles that hold vocabulary
     int Ls, NT, GK, NG;   // canonical sampler geometry (tg_gen.hip make_geom / oracle orc_span_len)
 };
@@ -48,7 +50,7 @@ Geom make_geom(const TgGenWeights& w) {
     Geom g;
     g.V = w.V; g.E = w.E; g.H = w.H;
     g.KBh = w.H / 16; g.KBe = w.E / 16; g.KBc = g.KBh + g.KBe;
-    g.MBp = 4 * ((w.V + 127) / 128);
+    g.MBp = 8 * ((w.V + 255) / 256);
     g.NT16 = (w.V + 15) / 16;
     g.Ls = 16 * ((w.V + 127) / 128);
     g.NT = g.Ls / 16;
@@ -90,7 +92,7 @@ Carve carve(const Geom& g, size_t rowsP, void* base) {
     return c;
 }
 
-size_t pad128(size_t r) { return (r + 127) / 128 * 128; }
+size_t pad128(size_t r) { return (r + 255) / 256 * 256; }  // whole row tiles of the larger GEMM shape
 
 // ------------------------------------------------------------------ per-call weight preparation
 __global__ __launch_bounds__(256) void k_genw_absmax(const float* x, size_t n, unsigned* out) {
@@ -251,14 +253,22 @@ struct GemmArgs {
     const float* gb; f32x4* cfrag; f32x4* hdst; int H;  // CELL epilogue
 };
 
-template <bool PROJ>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WM x WN waves, each TM x TN MFMA tiles of 32 x 32: workgroup tile (32 WM TM) x (32 WN TN).
+//   <2,2,2,2>  128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU   (small problems, 4H = 128)
+//   <2,4,4,2>  256 x 256, 512 threads, 128 KiB LDS, one workgroup per CU: half the operand bytes per flop -- at
+//              128 x 128 every CU pulls ~42 B/clk from L2, which bounds the kernel before the matrix pipes do
+template <bool PROJ, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_genw_gemm(const GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [2 buffers][A 1024 | B 1024] pieces = 64 KiB
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int MBT = WM * TM, RBT = WN * TN;          // 32-blocks per workgroup tile
+    constexpr int NLA = MBT * 256 / NTHR, NLB = RBT * 256 / NTHR;  // 16-B loads per thread and stage
+    constexpr int STAGE = (MBT + RBT) * 256;             // pieces per stage buffer
+    extern __shared__ __attribute__((aligned(16))) f32x4 lds[];  // [2 buffers][A MBT*256 | B RBT*256] pieces
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
-    const int wm = w >> 1, wn = w & 1;
+    const int wm = w / WN, wn = w % WN;
     // XCD-aware order: the workgroups that share an XCD (id % 8) walk consecutive logical ids; 8 consecutive ids
     // share one A tile, and one group of 8 row tiles stays put while the M tiles sweep (its B stays in that L2)
     const int nb = gridDim.x;
@@ -267,40 +277,48 @@ void k_genw_gemm(const GemmArgs a) {
     const int rtg = lb / per, rem = lb - rtg * per;
     const int mt = rem >> 3, rt = rtg * 8 + (rem & 7);
     if (rt >= a.RT) return;
-    const int mb0 = 4 * mt, rb0 = 4 * rt;
+    const int mb0 = MBT * mt, rb0 = RBT * rt;
     const int S = a.KB >> 1;
     const int Se = PROJ ? 0 : (a.KBe >> 1);
 
-    int tokr[4] = {0, 0, 0, 0};
+    // load i of a thread fetches piece p = tid + i*NTHR of the stage: 32-block p >> 8, piece p & 255 within the block's
+    // two k blocks ([kbl][part][lane])
+    const int pw = tid & 255;
+    int tokr[NLB];
     if constexpr (!PROJ) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tokr[i] = tg_min(tg_max(a.tok[(rb0 + i) * 32 + (tid & 31)], 0), a.V - 1);
+        for (int i = 0; i < NLB; ++i)
+            tokr[i] = tg_min(tg_max(a.tok[(rb0 + ((tid + i * NTHR) >> 8)) * 32 + (tid & 31)], 0), a.V - 1);
     }
-    f32x4 pa[4], pb[4];
+    f32x4 pa[NLA], pb[NLB];
     auto load_stage = [&](int s) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) pa[i] = a.A[((size_t)(mb0 + i) * a.KB + 2 * s) * 128 + tid];
+        for (int i = 0; i < NLA; ++i)
+            pa[i] = a.A[((size_t)(mb0 + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw];
         if (PROJ || s >= Se) {
             const int sh = s - Se;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pb[i] = a.Bh[((size_t)(rb0 + i) * a.KBh + 2 * sh) * 128 + tid];
+            for (int i = 0; i < NLB; ++i)
+                pb[i] = a.Bh[((size_t)(rb0 + ((tid + i * NTHR) >> 8)) * a.KBh + 2 * sh) * 128 + pw];
         } else {
-            const _Float16* tab = ((tid >> 6) & 1) ? a.emb_lo : a.emb_hi;
-            const int k = (2 * s + (tid >> 7)) * 16 + 8 * ((tid >> 5) & 1);
+            const _Float16* tab = ((pw >> 6) & 1) ? a.emb_lo : a.emb_hi;
+            const int k = (2 * s + (pw >> 7)) * 16 + 8 * ((pw >> 5) & 1);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) pb[i] = *reinterpret_cast<const f32x4*>(tab + (size_t)tokr[i] * a.E + k);
+            for (int i = 0; i < NLB; ++i) pb[i] = *reinterpret_cast<const f32x4*>(tab + (size_t)tokr[i] * a.E + k);
         }
     };
     auto store_stage = [&](int buf) {
-        f32x4* d = lds + buf * 2048 + tid;
+        f32x4* d = lds + buf * STAGE + tid;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { d[i * 256] = pa[i]; d[1024 + i * 256] = pb[i]; }
+        for (int i = 0; i < NLA; ++i) d[i * NTHR] = pa[i];
+#pragma unroll
+        for (int i = 0; i < NLB; ++i) d[MBT * 256 + i * NTHR] = pb[i];
     };
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
@@ -309,22 +327,25 @@ void k_genw_gemm(const GemmArgs a) {
     __syncthreads();
     for (int s = 0; s < S; ++s) {
         if (s + 1 < S) load_stage(s + 1);
-        const f32x4* la = lds + (s & 1) * 2048 + (2 * wm) * 256 + lane;
-        const f32x4* lbp = lds + (s & 1) * 2048 + 1024 + (2 * wn) * 256 + lane;
+        const f32x4* la = lds + (s & 1) * STAGE + (TM * wm) * 256 + lane;
+        const f32x4* lbp = lds + (s & 1) * STAGE + MBT * 256 + (TN * wn) * 256 + lane;
 #pragma unroll
         for (int kbl = 0; kbl < 2; ++kbl) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                ah[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128]);
-                al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
+            for (int i = 0; i < TN; ++i) {
                 bh[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128]);
                 bl[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128 + 64]);
             }
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128]);
+                al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
+            }
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) {
                     acc[mi][ni] = TG_MFMA16(al[mi], bh[ni], acc[mi][ni]);
                     acc[mi][ni] = TG_MFMA16(ah[mi], bl[ni], acc[mi][ni]);
                     acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
@@ -338,8 +359,8 @@ void k_genw_gemm(const GemmArgs a) {
         // per (row, 16-entry tile): m = max logit (base 2), s = sum 2^(l - m) in entry order
         const float inv = a.sc->invProj;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int mb = mb0 + 2 * wm + mi;
+        for (int mi = 0; mi < TM; ++mi) {
+            const int mb = mb0 + TM * wm + mi;
             float bias[16];
             const f32x4* pbias = reinterpret_cast<const f32x4*>(a.bias2 + 32 * mb + 16 * hh);
 #pragma unroll
@@ -349,8 +370,8 @@ void k_genw_gemm(const GemmArgs a) {
                 for (int e = 0; e < 4; ++e) bias[4 * q4 + e] = b4[e];
             }
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int row = (rb0 + 2 * wn + ni) * 32 + n;
+            for (int ni = 0; ni < TN; ++ni) {
+                const int row = (rb0 + TN * wn + ni) * 32 + n;
                 float l[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) l[r] = __builtin_fmaf(acc[mi][ni][r], inv, bias[r]);
@@ -370,15 +391,15 @@ void k_genw_gemm(const GemmArgs a) {
         const float inv = a.sc->invCell;
         const int H = a.H;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-            const int T = mb0 + 2 * wm + mi;
+        for (int mi = 0; mi < TM; ++mi) {
+            const int T = mb0 + TM * wm + mi;
             const int u0 = 8 * T + 4 * hh;
             f32x4 gbias[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) gbias[q] = *reinterpret_cast<const f32x4*>(a.gb + q * H + u0);
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int rb = rb0 + 2 * wn + ni;
+            for (int ni = 0; ni < TN; ++ni) {
+                const int rb = rb0 + TN * wn + ni;
                 f32x4* cp = a.cfrag + ((size_t)rb * (H >> 3) + T) * 64 + lane;
                 const f32x4 c_old = *cp;
                 f32x4 c_new, h_new;
@@ -659,20 +680,38 @@ __global__ __launch_bounds__(256) void k_genw_fill_tok(int* tok, size_t n, int v
         }                                                                  \
     } while (0)
 
-int ensure_lds() {
-    static thread_local bool done = false;
-    if (done) return TG_OK;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<true>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
-    if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+template <bool PROJ, int WM, int WN, int TM, int TN>
+int gemm_lds_attr() {
+    constexpr int bytes = 2 * (WM * TM + WN * TN) * 256 * 16;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<PROJ, WM, WN, TM, TN>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
         tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
         return TG_ERR_LAUNCH;
     }
+    return TG_OK;
+}
+
+int ensure_lds() {
+    static thread_local bool done = false;
+    if (done) return TG_OK;
+    int rc = gemm_lds_attr<true, 2, 2, 2, 2>();
+    if (!rc) rc = gemm_lds_attr<false, 2, 2, 2, 2>();
+    if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2>();
+    if (!rc) rc = gemm_lds_attr<false, 2, 4, 4, 2>();
+    if (rc) return rc;
     done = true;
     return TG_OK;
+}
+
+template <bool PROJ, int WM, int WN, int TM, int TN>
+void launch_gemm_t(GemmArgs a, int m_blocks, int rows, hipStream_t st) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr int bytes = 2 * (WM * TM + WN * TN) * 256 * 16;
+    a.MT = m_blocks * 32 / BM;
+    a.RT = (rows + BN - 1) / BN;
+    const int rtg = (a.RT + 7) / 8;
+    hipLaunchKernelGGL((k_genw_gemm<PROJ, WM, WN, TM, TN>), dim3(rtg * 8 * a.MT), dim3(64 * WM * WN), bytes, st, a);
 }
 
 int prep_weights(const TgGenWeights& w, const Geom& g, const Carve& c, hipStream_t st) {
@@ -705,33 +744,38 @@ int prep_weights(const TgGenWeights& w, const Geom& g, const Carve& c, hipStream
     return TG_OK;
 }
 
+// 256 x 256 tiles once the problem fills the chip with them and M divides; 128 x 128 otherwise
+bool big_tiles(int m_blocks, int rows) {
+    static const char* force = getenv("TG_GENW_TILE");  // diagnostic override: "128" or "256"
+    if (m_blocks % 8) return false;
+    if (force && force[0] == '1') return false;
+    if (force && force[0] == '2') return true;
+    return (long)(m_blocks / 8) * ((rows + 255) / 256) >= 256;
+}
+
 void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
                  int hdst, hipStream_t st) {
     GemmArgs a = {};
-    a.RT = (rows + 127) / 128;
     a.KBh = g.KBh;
     a.KBe = g.KBe;
     a.sc = c.sc;
     a.H = g.H;
     a.E = g.E;
     a.V = g.V;
-    const int rtg = (a.RT + 7) / 8;
+    a.Bh = c.hfrag[hsrc];
     if (proj) {
         a.A = c.a_proj;
         a.KB = g.KBh;
-        a.MT = g.MBp / 4;
-        a.Bh = c.hfrag[hsrc];
         a.bias2 = c.bias2;
         a.rec = c.rec;
         a.rowsP = rowsP;
         tg_prof_begin(TG_KERNEL_GENW_PROJ, st);
-        hipLaunchKernelGGL(k_genw_gemm<true>, dim3(rtg * 8 * a.MT), dim3(256), 65536, st, a);
+        if (big_tiles(g.MBp, rows)) launch_gemm_t<true, 2, 4, 4, 2>(a, g.MBp, rows, st);
+        else launch_gemm_t<true, 2, 2, 2, 2>(a, g.MBp, rows, st);
         tg_prof_end(st);
     } else {
         a.A = c.a_cell;
         a.KB = g.KBc;
-        a.MT = 4 * g.H / 128;
-        a.Bh = c.hfrag[hsrc];
         a.emb_hi = c.emb_hi;
         a.emb_lo = c.emb_lo;
         a.tok = c.tok;
@@ -739,7 +783,8 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         a.cfrag = c.cfrag;
         a.hdst = c.hfrag[hdst];
         tg_prof_begin(TG_KERNEL_GENW_CELL, st);
-        hipLaunchKernelGGL(k_genw_gemm<false>, dim3(rtg * 8 * a.MT), dim3(256), 65536, st, a);
+        if (big_tiles(4 * g.H / 32, rows)) launch_gemm_t<false, 2, 4, 4, 2>(a, 4 * g.H / 32, rows, st);
+        else launch_gemm_t<false, 2, 2, 2, 2>(a, 4 * g.H / 32, rows, st);
         tg_prof_end(st);
     }
 }
