@@ -27,6 +27,8 @@ WORKLOADS = {
     "c1": dict(V=5000, L=20, E=32, H=32, B=64, R=16, desc="configs[0] SeqGAN oracle synthetic"),
     "c2": dict(V=5255, L=51, E=32, H=32, B=64, R=16, desc="configs[1] SeqGAN real-data shape (EMNLP-News-like)"),
     "c3s": dict(V=32000, L=51, E=512, H=512, B=4096, R=1, desc="configs[2] scaled rollout, 1/64 slice (rollout_num 1 of 64)"),
+    "c3": dict(V=32000, L=51, E=512, H=512, B=4096, R=64, strong=True,
+               desc="configs[2] scaled rollout, full size (rollout_num 64 in total, sharded over the ranks)"),
     "c4": dict(V=5000, L=20, E=32, H=32, B=64, R=16, k=4, dis="sentigan",
                desc="configs[3] SentiGAN k=4 generators, shared 5-way CNN_D, 4 sequential get_reward calls"),
 }
@@ -267,7 +269,11 @@ def main():
         return bench_pg(args, dev)
     wl = WORKLOADS[args.workload]
     V, L, E, H, B = wl["V"], wl["L"], wl["E"], wl["H"], wl["B"]
-    R = wl["R"] * world  # weak scaling: rollout_num 16 per GPU
+    strong = bool(wl.get("strong"))
+    if strong and wl["R"] % world:
+        raise SystemExit("workload %s shards rollout_num %d over the ranks: --gpus must divide it" % (args.workload, wl["R"]))
+    R = wl["R"] if strong else wl["R"] * world  # weak scaling: rollout_num 16 per GPU; c3: 64 in total
+    r_local = R // world                        # rollout indices one rank's launches process
     k_gens = wl.get("k", 1)
     std = 1.0 if H == 32 else 0.05   # N(0,1) "oracle" weights (generator.py:97-100); small std at H = 512
     gens = [tg.modules.synthetic_generator(V, E, H, L, seed=i, std=std, device=dev) for i in range(k_gens)]
@@ -322,17 +328,17 @@ def main():
         completions = B * R * L * k_gens  # whole job, per step
         filt = tg.synth.SENTIGAN_D_FILTERS if dis_kind == "sentigan" else tg.synth.SEQGAN_D_FILTERS
         conv_f, conv_fresh_bi, hw_f, gen_f = flops_model(V, L, E, H, filt, n_out=dis.feature2out.out_features)
-        n_local = B * wl["R"] * L  # sequences one rank's launches process per get_reward call
+        n_local = B * r_local * L  # sequences one rank's launches process per get_reward call
         split = (args.dis_precision or tg._lib.default_dis_precision) == "split_f16"
         gsplit = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and E == 32 and H == 32
         # flops one launch EXECUTES (prefix-reuse conv: fresh windows only); the reference-equivalent conv work
         # (every window of every completion) is reported beside it
         gwide = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and not (E == 32 and H == 32)
-        draws = B * wl["R"] * L * (L - 1) // 2            # sampled tokens of one rank's call
-        cell_steps = B * wl["R"] * (L - 1) * (L - 2) // 2  # wide path: rows enter with their prefix state, no cell step
+        draws = B * r_local * L * (L - 1) // 2            # sampled tokens of one rank's call
+        cell_steps = B * r_local * (L - 1) * (L - 2) // 2  # wide path: rows enter with their prefix state, no cell step
         # flops one rank EXECUTES per get_reward call, per kernel (prefix-reuse conv: fresh windows only; the
         # reference-equivalent conv work, every window of every completion, is reported beside it)
-        per_call = {"dis_conv": conv_fresh_bi * B * wl["R"], "dis_highway": hw_f * n_local,
+        per_call = {"dis_conv": conv_fresh_bi * B * r_local, "dis_highway": hw_f * n_local,
                     "gen_sample": gen_f * draws, "genw_proj": 2 * H * V * draws, "genw_cell": 8 * H * (E + H) * cell_steps}
         f16 = {"dis_conv": split, "dis_highway": split, "gen_sample": gsplit, "genw_proj": True, "genw_cell": True}
         peaks = {k: PEAK_F16_MFMA_TFLOPS if v else PEAK_FP32_MFMA_TFLOPS for k, v in f16.items()}
@@ -354,13 +360,13 @@ def main():
         out = {
             "metric": "MC rollout completions/sec", "value": completions * args.steps / dt, "unit": "completions/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
             "dtype": "f32" + (" (split-f16 x3 operands, f32 accumulate: %s)" % ", ".join(
                 (["generator projection"] if gsplit else []) + (["generator gates and projection"] if gwide else []) +
                 (["scorer conv/highway"] if split else []))
                 if (split or gsplit or gwide) else ""), "data": "synthetic",
             "config": {"workload": "%s: vocab %d, len %d, emb/hidden %d, batch %d, rollout_num %d per GPU (%d total), "
-                                   "%s scorer%s" % (wl["desc"], V, L, H, B, wl["R"], R, dis_kind,
+                                   "%s scorer%s" % (wl["desc"], V, L, H, B, r_local, R, dis_kind,
                                                     " eval mode" if args.eval_mode else " with live dropout"),
                        "completions_per_step": completions, "sharding": "rollout index over %d rank(s)" % world},
             "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peaks[dom],

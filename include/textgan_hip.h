@@ -56,8 +56,8 @@ typedef struct TgGenWeights {
  *                     fp16 MFMAs per product with fp32 accumulation, bias added exactly; logits move by ~1e-6.
  *                     E = H = 32 (every SeqGAN / SentiGAN config of the reference): inside the persistent kernel.
  *                     Other shapes (E, H multiples of 32, V <= 32768 -- the scaled config): tg_gen_rollout and
- *                     tg_gen_sample run step-synchronous split-fp16 GEMMs for the gates and the projection
- *                     (tg_genw.hip); tg_gen_teacher_forced / tg_gen_nll stay fp32 there. */
+ *                     tg_gen_sample / tg_gen_nll run step-synchronous split-fp16 GEMMs for the gates and the
+ *                     projection (tg_genw.hip); tg_gen_teacher_forced stays fp32 there. */
 #define TG_GEN_FP32 0
 #define TG_GEN_SPLIT_F16 1
 
@@ -127,8 +127,10 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
  * of each target token), honouring w->precision.  With TG_GEN_SPLIT_F16 (E = H = 32) the log-sum-exp comes from
  * the split-fp16 projection (probabilities within ~1e-6 relative of fp32) while the target's own logit is an exact
  * fp32 dot product; with TG_GEN_FP32, or any other shape, the result is tg_gen_teacher_forced's, bit for bit.
- *   logp_out [N,L] required; lse_out [N,L] or NULL; workspace of tg_gen_nll_workspace_bytes(w) (0 for fp32). */
-size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w);
+ * Shapes beyond E = H = 32 with TG_GEN_SPLIT_F16: the step-synchronous GEMM path of tg_genw.hip (cell and projection
+ * on split-fp16 MFMAs, log-sum-exp from the per-tile records, the target's logit an fp32 dot product).
+ *   logp_out [N,L] required; lse_out [N,L] or NULL; workspace of tg_gen_nll_workspace_bytes(w, N) (0 for fp32). */
+size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w, int N);
 int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target,
                int N, int L, float* logp_out, float* lse_out, void* workspace,
                size_t workspace_bytes, void* stream);

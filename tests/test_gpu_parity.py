@@ -199,6 +199,28 @@ def test_sample_wide_shapes_against_oracle(V, E, H, N, L, std):
         assert (free == ref).all(-1).mean() >= 0.97
 
 
+@pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1), (4099, 512, 512, 19, 4, 0.05)])
+def test_nll_wide_shapes_against_oracle(V, E, H, N, L, std):
+    """tg_gen_nll beyond E = H = 32: split_f16 takes the GEMM path (log-sum-exp from the tile records, the target's
+    logit an fp32 dot product), fp32 the persistent kernel; both within the 1e-5 NLL bar of the oracle."""
+    gsd = synth.gen_state(V, E, H, seed=14, std=std)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    tgt = synth.tokens(24, (N, L), V)
+    inp = np.concatenate([np.ones((N, 1), np.int64), tgt[:, :-1]], 1)
+    o = oracle.gen_teacher_forced(og, inp, tgt)
+    for precision in GEN_PRECISIONS:
+        tg._lib.profile_enable(True)
+        tg._lib.profile_read()
+        lp, lse = tg.ops.gen_nll(gen, _t(inp), _t(tgt), precision=precision, want_lse=True)
+        prof = tg._lib.profile_read()
+        tg._lib.profile_enable(False)
+        assert (prof["genw_proj"][1] > 0) == (precision == "split_f16")
+        np.testing.assert_allclose(lse.cpu().numpy(), o["lse"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(lp.cpu().numpy(), o["logp"], rtol=1e-5, atol=1e-5)
+        assert abs(float(-lp.mean()) - float(-o["logp"].mean())) <= 1e-5 * abs(float(o["logp"].mean()))
+
+
 @pytest.mark.parametrize("std,emb_scale,bias_scale", [(0.01, 1.0, 1.0), (2.0, 1.0, 1.0), (0.3, 1e-3, 30.0), (0.3, 50.0, 1.0)])
 def test_wide_generator_across_weight_scales(std, emb_scale, bias_scale):
     """The wide path scales W_out, W_ih, W_hh and the embedding table by powers of two taken from their |max| and

@@ -70,3 +70,23 @@ def test_synth_is_deterministic_and_shaped():
     assert u.dtype == np.float32 and u.min() >= 0 and u.max() < 1
     g = tg.modules.synthetic_generator(100, 32, 32, 20, device="cpu")
     assert sorted(g.state_dict()) == sorted(a)
+
+
+def test_wide_generator_workspace_is_bounded_by_the_chunk():
+    """tg_gen_rollout_workspace_bytes (host arithmetic only): E = H = 32 needs the prefix states and the split W_out
+    fragments; other shapes in split_f16 add one chunk of at most 2^18 completions of the GEMM path (tg_genw.hip),
+    whatever rollout_num is."""
+    import ctypes as C
+    lib = tg._lib.lib()
+
+    def ws(V, E, H, B, L, R, prec):
+        w = tg._lib.GenW(*([1] * 7), V, E, H, tg._lib.PRECISIONS[prec])  # pointers are not dereferenced
+        return lib.tg_gen_rollout_workspace_bytes(C.byref(w), B, L, R)
+
+    small = ws(5255, 32, 32, 64, 51, 16, "split_f16")
+    assert small < 4 << 20 and small == ws(5255, 32, 32, 64, 51, 64, "split_f16")
+    one, many = ws(32000, 512, 512, 4096, 51, 1, "split_f16"), ws(32000, 512, 512, 4096, 51, 64, "split_f16")
+    assert one == many and 4 << 30 < one < 8 << 30          # one rollout index = 208 896 rows is already a chunk
+    assert ws(32000, 512, 512, 4096, 51, 64, "fp32") < 1 << 30   # persistent kernel: prefix states only
+    assert ws(3000, 64, 128, 8, 20, 2, "split_f16") < ws(3000, 64, 128, 8, 20, 200, "split_f16") \
+        <= ws(3000, 64, 128, 8, 20, 100000, "split_f16") < 2 << 30

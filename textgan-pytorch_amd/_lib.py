@@ -85,7 +85,7 @@ def lib():
                                                            C.c_size_t, C.c_void_p]
         l.tg_gen_pg_backward.restype = C.c_int
         l.tg_gen_nll_workspace_bytes.restype = C.c_size_t
-        l.tg_gen_nll_workspace_bytes.argtypes = [C.c_void_p]
+        l.tg_gen_nll_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
         l.tg_gen_nll.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
         l.tg_gen_nll.restype = C.c_int
         l.tg_gen_pg_forward.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4

@@ -1071,7 +1071,8 @@ extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, 
     return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
 }
 
-extern "C" size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w) {
+extern "C" size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w, int N) {
+    if (w && tg_genw_applies(w)) return tg_genw_nll_workspace_bytes(w, N);
     return (w && use_split(*w)) ? split_bytes(make_geom(w->V)) : 0;
 }
 
@@ -1084,6 +1085,8 @@ extern "C" int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;
+    if (tg_genw_applies(w))
+        return tg_genw_nll(w, inp, target, N, L, logp_out, lse_out, workspace, workspace_bytes, (hipStream_t)stream);
     GenArgs a = {};
     a.w = *w;
     a.geo = make_geom(w->V);
@@ -1095,8 +1098,8 @@ extern "C" int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64
     a.lse_out = lse_out;
     a.need_proj = 1;
     if (use_split(*w)) {
-        if (!workspace || workspace_bytes < tg_gen_nll_workspace_bytes(w)) {
-            tg_set_error("tg_gen_nll: workspace too small (%zu < %zu)", workspace_bytes, tg_gen_nll_workspace_bytes(w));
+        if (!workspace || workspace_bytes < tg_gen_nll_workspace_bytes(w, N)) {
+            tg_set_error("tg_gen_nll: workspace too small (%zu < %zu)", workspace_bytes, tg_gen_nll_workspace_bytes(w, N));
             return TG_ERR_WORKSPACE;
         }
         rc = prepare_split(a, workspace, (hipStream_t)stream);
@@ -1137,15 +1140,15 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
                      tg_gen_rollout_workspace_bytes(w, B, L, i_hi - i_lo));
         return TG_ERR_WORKSPACE;
     }
-    // 1) prefix states: teacher-forced pass over the sentences, no projection (rollout.py:35-38)
-    rc = tg_gen_teacher_forced(w, sentences, nullptr, B, L, nullptr, nullptr, nullptr, (float*)workspace, stream);
-    if (rc) return rc;
     if (tg_genw_applies(w)) {  // shapes beyond E = H = 32 in split-fp16: step-synchronous GEMMs (tg_genw.hip)
         const size_t sb = states_bytes(B, L, w->H);
         return tg_genw_rollout(w, sentences, B, L, g_lo, g_hi, i_lo, i_hi, uniforms, forced, completions,
-                               (const float*)workspace, reinterpret_cast<char*>(workspace) + sb, workspace_bytes - sb,
+                               (float*)workspace, reinterpret_cast<char*>(workspace) + sb, workspace_bytes - sb,
                                (hipStream_t)stream);
     }
+    // 1) prefix states: teacher-forced pass over the sentences, no projection (rollout.py:35-38)
+    rc = tg_gen_teacher_forced(w, sentences, nullptr, B, L, nullptr, nullptr, nullptr, (float*)workspace, stream);
+    if (rc) return rc;
     // 2) all completions; tiles ordered by given_num ascending (longest first)
     GenArgs a = {};
     a.w = *w;

@@ -8,13 +8,15 @@
 //   k_genw_gemm<PROJ>  logits[V x rows] = W_out . h (+ bias), per 16-entry tile a (max, sum 2^(l-max))
 //                      record -- logits never reach HBM
 //   k_genw_draw        canonical inverse-CDF draw from the records; only the 16
-//                      logits of the chosen tile are recomputed
-// Both GEMMs: 128 x 128 tile, K steps of 32 through LDS (two buffers, one barrier per step, next step's
-// operands in flight in registers), 4 waves x (2 x 2) 32x32x16 fp16 MFMA tiles, three products per
-// operand pair (hi.hi + hi.lo + lo.hi, fp32 accumulation) exactly as the split arithmetic of tg_gen.hip /
-// tg_dis.hip.  Every operand is kept in HBM in MFMA fragment order ("piece" = the 16 B one lane feeds to
-// one MFMA), so staging is a linear copy and every LDS read is a conflict-free 1-KiB row.
-// Replaces models/generator.py:40-84 and utils/rollout.py:25-55 of the reference for those shapes.
+//                      logits of the chosen tile are recomputed            (tg_gen_rollout, tg_gen_sample)
+//   k_genw_lse         log-sum-exp from the records + the target's logit    (tg_gen_nll)
+// Both GEMMs: 128 x 128 or 256 x 256 tile, K steps of 32 through LDS (two buffers, one barrier per step, next
+// step's operands in flight in registers), 32x32x16 fp16 MFMA tiles, three products per operand pair
+// (hi.hi + hi.lo + lo.hi, fp32 accumulation) exactly as the split arithmetic of tg_gen.hip / tg_dis.hip.
+// Every operand is kept in HBM in MFMA fragment order ("piece" = the 16 B one lane feeds to one MFMA), so
+// staging is a linear copy and every LDS read is a conflict-free 1-KiB row.
+// Replaces models/generator.py:40-84, utils/rollout.py:25-55 and the forward inside metrics/nll.py:59-61 of the
+// reference for those shapes.
 #include <stdlib.h>
 
 #include <type_traits>
@@ -31,7 +33,8 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr float kHScale = 8192.f;  // h in (-1, 1) -> below 2^13 in fp16
 constexpr float kL2E = 1.44269502162933349609375f;
 constexpr int kChunkRows = 1 << 18;  // rows (completions) advanced together
-constexpr int kMaxNG = 32;           // groups per span the draw kernel holds in registers (V <= 32768)
+constexpr int kMaxNG = 32;           // groups per span the draw kernel handles (V <= 32768)
+constexpr int kDrawRows = 16;        // rows per workgroup of the record-scanning kernels (draw, lse)
 
 struct Scales {  // device side, written by k_genw_prep
     float sWout, invProj;  // W_out*log2(e) scale, 1/(sWout * kHScale)
@@ -241,15 +244,22 @@ __global__ __launch_bounds__(256) void k_genw_enter(const float* __restrict__ sr
     cfrag[((size_t)(row >> 5) * (H >> 3) + T) * 64 + hh * 32 + (row & 31)] = c;
 }
 
+// Sampler records: one (max, sum) pair per (row, 16-entry tile), in blocks of 16 rows -- [row/16][tile][row%16] -- so
+// that the 16 rows one draw workgroup scans are one contiguous range.
+__device__ __forceinline__ size_t rec_index(int row, int tile, int ntiles) {
+    return ((size_t)(row >> 4) * ntiles + tile) * 16 + (row & 15);
+}
+
 // ------------------------------------------------------------------ the GEMM
 struct GemmArgs {
     const f32x4* A;   // fragments [MB][KB][2][64]
-    int KB, MT, RT;   // k blocks, 128-row M tiles, 128-row N (completion) tiles
+    int KB, MT, RT;   // k blocks, M tiles, N (completion) tiles of the workgroup shape
+    int NB;           // logical tiles: 8 * MT * ceil(RT / 8)
     const f32x4* Bh;  // hfrag (PROJ: the whole B operand; CELL: k blocks KBe..)
     int KBh, KBe;
     const _Float16* emb_hi; const _Float16* emb_lo; const int* tok; int E, V;  // CELL: x = emb[tok], gathered
     const Scales* sc;
-    const float* bias2; float2* rec; size_t rowsP;  // PROJ epilogue
+    const float* bias2; float2* rec; int ntiles;  // PROJ epilogue
     const float* gb; f32x4* cfrag; f32x4* hdst; int H;  // CELL epilogue
 };
 
@@ -269,42 +279,58 @@ void k_genw_gemm(const GemmArgs a) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
     const int wm = w / WN, wn = w % WN;
-    // XCD-aware order: the workgroups that share an XCD (id % 8) walk consecutive logical ids; 8 consecutive ids
-    // share one A tile, and one group of 8 row tiles stays put while the M tiles sweep (its B stays in that L2)
-    const int nb = gridDim.x;
-    const int lb = (blockIdx.x & 7) * (nb >> 3) + (blockIdx.x >> 3);
+    // XCD-aware order: the workgroups that share an XCD (id % 8) walk consecutive logical tile ids; 8 consecutive ids
+    // share one A tile, and one group of 8 row tiles stays put while the M tiles sweep (its B stays in that L2).
+    // a.NB logical tiles (a multiple of 8) over gridDim.x workgroups (a multiple of 8, <= NB): a workgroup takes every
+    // (gridDim.x / 8)-th tile of its XCD's range and fetches the next tile's first stage under the current tile's
+    // last one, so the fill latency is paid once per workgroup, not once per tile.
+    const int per_xcd = a.NB >> 3, stride = gridDim.x >> 3;
+    const int lb_end = ((int)blockIdx.x & 7) * per_xcd + per_xcd;
     const int per = 8 * a.MT;
-    const int rtg = lb / per, rem = lb - rtg * per;
-    const int mt = rem >> 3, rt = rtg * 8 + (rem & 7);
-    if (rt >= a.RT) return;
-    const int mb0 = MBT * mt, rb0 = RBT * rt;
+    auto decode = [&](int lb, int& mb0, int& rb0) {
+        const int rtg = lb / per, rem = lb - rtg * per;
+        const int rt = rtg * 8 + (rem & 7);
+        mb0 = MBT * (rem >> 3);
+        rb0 = RBT * rt;
+        return rt < a.RT;
+    };
+    auto next_valid = [&](int lb, int& mb0, int& rb0) {  // first tile at or after lb (in steps of stride) that has rows
+        while (lb < lb_end && !decode(lb, mb0, rb0)) lb += stride;
+        return lb;
+    };
+    int mb0 = 0, rb0 = 0;
+    int lb = next_valid(((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3), mb0, rb0);
+    if (lb >= lb_end) return;
     const int S = a.KB >> 1;
     const int Se = PROJ ? 0 : (a.KBe >> 1);
 
     // load i of a thread fetches piece p = tid + i*NTHR of the stage: 32-block p >> 8, piece p & 255 within the block's
     // two k blocks ([kbl][part][lane])
     const int pw = tid & 255;
-    int tokr[NLB];
-    if constexpr (!PROJ) {
+    int tokr[NLB], tokn[NLB];
+    auto load_tok = [&](int rb, int (&t)[NLB]) {
+        if constexpr (!PROJ) {
 #pragma unroll
-        for (int i = 0; i < NLB; ++i)
-            tokr[i] = tg_min(tg_max(a.tok[(rb0 + ((tid + i * NTHR) >> 8)) * 32 + (tid & 31)], 0), a.V - 1);
-    }
+            for (int i = 0; i < NLB; ++i)
+                t[i] = tg_min(tg_max(a.tok[(rb + ((tid + i * NTHR) >> 8)) * 32 + (tid & 31)], 0), a.V - 1);
+        }
+    };
+    load_tok(rb0, tokr);
     f32x4 pa[NLA], pb[NLB];
-    auto load_stage = [&](int s) {
+    auto load_stage = [&](int mb, int rb, const int (&tk)[NLB], int s) {
 #pragma unroll
         for (int i = 0; i < NLA; ++i)
-            pa[i] = a.A[((size_t)(mb0 + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw];
+            pa[i] = a.A[((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw];
         if (PROJ || s >= Se) {
             const int sh = s - Se;
 #pragma unroll
             for (int i = 0; i < NLB; ++i)
-                pb[i] = a.Bh[((size_t)(rb0 + ((tid + i * NTHR) >> 8)) * a.KBh + 2 * sh) * 128 + pw];
+                pb[i] = a.Bh[((size_t)(rb + ((tid + i * NTHR) >> 8)) * a.KBh + 2 * sh) * 128 + pw];
         } else {
             const _Float16* tab = ((pw >> 6) & 1) ? a.emb_lo : a.emb_hi;
             const int k = (2 * s + (pw >> 7)) * 16 + 8 * ((pw >> 5) & 1);
 #pragma unroll
-            for (int i = 0; i < NLB; ++i) pb[i] = *reinterpret_cast<const f32x4*>(tab + (size_t)tokr[i] * a.E + k);
+            for (int i = 0; i < NLB; ++i) pb[i] = *reinterpret_cast<const f32x4*>(tab + (size_t)tk[i] * a.E + k);
         }
     };
     auto store_stage = [&](int buf) {
@@ -315,20 +341,28 @@ void k_genw_gemm(const GemmArgs a) {
         for (int i = 0; i < NLB; ++i) d[MBT * 256 + i * NTHR] = pb[i];
     };
     f32x16 acc[TM][TN];
+
+    load_stage(mb0, rb0, tokr, 0);
+    store_stage(0);
+    __syncthreads();
+    int gs = 0;  // stages done by this workgroup: buffer parity
+    for (;;) {
+    int nmb0 = 0, nrb0 = 0;
+    const int nlb = next_valid(lb + stride, nmb0, nrb0);
+    const bool has_next = nlb < lb_end;
+    if (has_next) load_tok(nrb0, tokn);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-
-    load_stage(0);
-    store_stage(0);
-    __syncthreads();
-    for (int s = 0; s < S; ++s) {
-        if (s + 1 < S) load_stage(s + 1);
-        const f32x4* la = lds + (s & 1) * STAGE + (TM * wm) * 256 + lane;
-        const f32x4* lbp = lds + (s & 1) * STAGE + MBT * 256 + (TN * wn) * 256 + lane;
+    for (int s = 0; s < S; ++s, ++gs) {
+        const bool more = s + 1 < S || has_next;
+        if (s + 1 < S) load_stage(mb0, rb0, tokr, s + 1);
+        else if (has_next) load_stage(nmb0, nrb0, tokn, 0);
+        const f32x4* la = lds + (gs & 1) * STAGE + (TM * wm) * 256 + lane;
+        const f32x4* lbp = lds + (gs & 1) * STAGE + MBT * 256 + (TN * wn) * 256 + lane;
 #pragma unroll
         for (int kbl = 0; kbl < 2; ++kbl) {
             f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -342,16 +376,23 @@ void k_genw_gemm(const GemmArgs a) {
                 ah[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128]);
                 al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
             }
+            // product-major: TM*TN independent accumulators between two MFMAs on the same one
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < TN; ++ni) {
-                    acc[mi][ni] = TG_MFMA16(al[mi], bh[ni], acc[mi][ni]);
-                    acc[mi][ni] = TG_MFMA16(ah[mi], bl[ni], acc[mi][ni]);
-                    acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
-                }
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(al[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bl[ni], acc[mi][ni]);
+#pragma unroll
+            for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
+            // the next stage goes to the other buffer (last read before the previous barrier) while the first k
+            // block's MFMAs are still draining
+            if (kbl == 0 && more) store_stage((gs + 1) & 1);
         }
-        if (s + 1 < S) store_stage((s + 1) & 1);
         __syncthreads();
     }
 
@@ -384,7 +425,9 @@ void k_genw_gemm(const GemmArgs a) {
                 float s = 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s += ev[r];
-                a.rec[(size_t)(2 * mb + hh) * a.rowsP + row] = make_float2(m, s);
+                // streamed once, read once by the draw kernel: keep it out of the L2 the operand tiles live in
+                __builtin_nontemporal_store(__builtin_bit_cast(double, make_float2(m, s)),
+                                            reinterpret_cast<double*>(a.rec + rec_index(row, 2 * mb + hh, a.ntiles)));
             }
         }
     } else {
@@ -418,6 +461,113 @@ void k_genw_gemm(const GemmArgs a) {
             }
         }
     }
+    if (!has_next) break;
+    lb = nlb;
+    mb0 = nmb0;
+    rb0 = nrb0;
+#pragma unroll
+    for (int i = 0; i < NLB; ++i) tokr[i] = tokn[i];
+    }  // tiles of this workgroup
+}
+
+// prefix chain (the states rollout rows enter with, utils/rollout.py:35-38): rows 0..B-1 are the sentences themselves,
+// advanced by teacher forcing; after each step their state is exported in tg_gen_teacher_forced's layout [B][2][H].
+__global__ __launch_bounds__(256) void k_genw_tok_col(const int64_t* __restrict__ sentences, int B, int L, int t, int V,
+                                                      int* __restrict__ tok) {
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    if (b < B) tok[b] = tg_min(tg_max((int)sentences[(size_t)b * L + t], 0), V - 1);
+}
+
+// Teacher-forced log-probabilities from the tile records (metrics/nll.py:59-61): 16 rows per workgroup, 32 threads per
+// row.  lse = log-sum-exp over the records (per-thread online (max, sum), merged in fp64); the target's own logit is
+// an fp32 dot product of its W_out row with h = (hi + lo) / 2^13.
+struct LseArgs {
+    Geom g;
+    const float2* rec; int ntiles;
+    int rows, t, L;
+    const int64_t* target;  // [rows, L] (chunk base)
+    float* logp; float* lse;  // [rows, L] (chunk base); lse nullable
+    const f32x4* hfrag; const float* w_out; const float* b_out;
+};
+__global__ __launch_bounds__(512) void k_genw_lse(const LseArgs a) {
+    __shared__ float mb[kDrawRows][32];
+    __shared__ double sb[kDrawRows][32];
+    __shared__ float db[kDrawRows][32];
+    const int tid = threadIdx.x, r16 = tid & 15, sg = tid >> 4;
+    const int row = blockIdx.x * kDrawRows + r16;
+    const bool valid = row < a.rows;
+    const int rowc = valid ? row : a.rows - 1;
+    const int NT16 = a.g.NT16, V = a.g.V, H = a.g.H;
+    const float2* rp = a.rec + rec_index(rowc, 0, a.ntiles);
+    float m = TG_NEG_BIG, s = 0.f;
+    for (int q0 = sg; q0 < NT16; q0 += 32 * 8) {
+        float2 r[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int q = q0 + 32 * i;
+            const float2 v = rp[tg_min(q, NT16 - 1) * 16];
+            r[i] = q < NT16 ? v : make_float2(TG_NEG_BIG, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float mn = __builtin_fmaxf(m, r[i].x);
+            s = s * __builtin_amdgcn_exp2f(m - mn) + r[i].y * __builtin_amdgcn_exp2f(r[i].x - mn);
+            m = mn;
+        }
+    }
+    mb[r16][sg] = m;
+    // the target's logit: thread sg takes the 16-B slices sg, sg+32, .. of the weight row
+    const size_t o = (size_t)rowc * a.L + a.t;
+    const int tv = tg_min(tg_max((int)a.target[o], 0), V - 1);
+    {
+        const int rb = rowc >> 5, j = rowc & 31;
+        const char* hb = reinterpret_cast<const char*>(a.hfrag);
+        float d = 0.f;
+        for (int k4 = sg; k4 < (H >> 2); k4 += 32) {
+            const int k0 = 4 * k4;
+            const size_t piece = ((size_t)(rb * a.g.KBh + (k0 >> 4)) * 2) * 64 + ((k0 >> 3) & 1) * 32 + j;
+            const f16x4 hi = *reinterpret_cast<const f16x4*>(hb + piece * 16 + 2 * (k0 & 7));
+            const f16x4 lo = *reinterpret_cast<const f16x4*>(hb + (piece + 64) * 16 + 2 * (k0 & 7));
+            const f32x4 wv = *reinterpret_cast<const f32x4*>(a.w_out + (size_t)tv * H + k0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d = __builtin_fmaf(wv[e], ((float)hi[e] + (float)lo[e]) * (1.f / kHScale), d);
+        }
+        db[r16][sg] = d;
+    }
+    __syncthreads();
+    float M = mb[r16][0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) M = __builtin_fmaxf(M, mb[r16][i]);
+    sb[r16][sg] = (double)s * exp2((double)m - (double)M);
+    __syncthreads();
+    if (tid < kDrawRows && valid) {
+        double S = 0.0;
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) { S += sb[r16][i]; d += db[r16][i]; }
+        const float lse = (float)(((double)M + log2(S)) * 0.69314718055994530942);
+        if (a.lse) a.lse[o] = lse;
+        a.logp[o] = (d + a.b_out[tv]) - lse;
+    }
+}
+__global__ __launch_bounds__(256) void k_genw_export(const f32x4* __restrict__ hfrag, const f32x4* __restrict__ cfrag, int B,
+                                                     int H, int KBh, float* __restrict__ dst) {
+    const int q = H >> 2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)B * q) return;
+    const int row = (int)(idx / q), uq = (int)(idx - (size_t)row * q);
+    const int T = uq >> 1, hh = uq & 1;
+    const int rb = row >> 5, j = row & 31, kb = T >> 1, kh = T & 1;
+    const size_t piece = ((size_t)(rb * KBh + kb) * 2) * 64 + kh * 32 + j;
+    const char* p = reinterpret_cast<const char*>(hfrag);
+    const f16x4 hi = *reinterpret_cast<const f16x4*>(p + piece * 16 + 8 * hh);
+    const f16x4 lo = *reinterpret_cast<const f16x4*>(p + (piece + 64) * 16 + 8 * hh);
+    f32x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = ((float)hi[e] + (float)lo[e]) * (1.f / kHScale);  // exact: 22 bits, power-of-two scale
+    float* d = dst + (size_t)row * 2 * H + 4 * uq;
+    *reinterpret_cast<f32x4*>(d) = h;
+    *reinterpret_cast<f32x4*>(d + H) = cfrag[((size_t)rb * (H >> 3) + T) * 64 + hh * 32 + j];
 }
 
 // ------------------------------------------------------------------ row <-> output mapping
@@ -458,39 +608,39 @@ __global__ __launch_bounds__(256) void k_genw_prefix(const int64_t* __restrict__
 struct DrawArgs {
     Geom g;
     RowMap map;
-    const float2* rec; size_t rowsP;
+    const float2* rec; int ntiles;
     int A, t;                    // active rows, position being drawn
     const float* uniforms; const int64_t* forced; int64_t* out; int* tok;
     const f32x4* hfrag; const float* w_out; const float* bias2;
 };
 
-// 64 rows per workgroup; wave = span, lane = row for the scans; 8 consecutive lanes per row for the recompute.
-// Same decisions as oracle canonical_draw: tile sums (fp32, entry order) -> group sums (fp32, tile order) -> span
-// sums / total / target / every prefix comparison in fp64.  Tile sums come from the records at their own maximum and
-// are moved to the group's maximum in fp32, the group sums to the row's maximum in fp64.
+// 16 rows per workgroup of 512 threads.  Same decisions as oracle canonical_draw: tile sums (fp32, entry order) ->
+// group sums (fp32, tile order) -> span sums / total / target / every prefix comparison in fp64.  Tile sums come from
+// the records at their own maximum and are moved to the group's maximum in fp32, the group sums to the row's maximum
+// in fp64.
+//   scan     thread (row, span, quarter): 8 of the span's <= 32 groups, their 64 records fetched 32 at a time
+//   select   thread (row, span): span sum in group order, then the owner of the chosen span walks groups and tiles
+//   logits   32 threads per row recompute the chosen tile's 16 logits (4 entries x an eighth of k each)
 __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
-    __shared__ float mbuf[8][64];
-    __shared__ double sbuf[8][64];
-    __shared__ int selT[64];
-    __shared__ double selp[64], tgt[64];
-    __shared__ float Mrow[64];
-    __shared__ float wbuf[64][17];
-    const int tid = threadIdx.x, sp = tid >> 6, ln = tid & 63;
-    const int row = blockIdx.x * 64 + ln;
+    __shared__ double cqb[kDrawRows][8][kMaxNG];  // (max, sum) pairs of the groups, then their fp64 contributions
+    __shared__ float mxb[kDrawRows][32];
+    __shared__ double sbuf[8][kDrawRows];
+    __shared__ int selT[kDrawRows];
+    __shared__ double selp[kDrawRows], tgt[kDrawRows];
+    __shared__ float Mrow[kDrawRows];
+    __shared__ float wbuf[kDrawRows][17];
+    const int tid = threadIdx.x, r16 = tid & 15, sg = tid >> 4;
+    const int row = blockIdx.x * kDrawRows + r16;
     const bool valid = row < a.A;
     const int rowc = valid ? row : a.A - 1;
     const int NT = a.g.NT, GK = a.g.GK, V = a.g.V;
-    const int ntv = tg_min(tg_max(a.g.NT16 - sp * NT, 0), NT);  // tiles of this span that hold vocabulary
-    const int ngv = (ntv + GK - 1) / GK;
-    const size_t rs = a.rowsP;
-    const float2* rp = a.rec + (size_t)(sp * NT) * rs + rowc;
-
-    auto load_group = [&](int gq, float2 (&r)[8]) {
+    auto span_tiles = [&](int s) { return tg_min(tg_max(a.g.NT16 - s * NT, 0), NT); };  // tiles that hold vocabulary
+    auto load_group = [&](const float2* rp, int ntv, int gq, float2 (&r)[8]) {
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) {
             const int q = gq * GK + tt;
-            r[tt] = make_float2(TG_NEG_BIG, 0.f);
-            if (tt < GK && q < ntv) r[tt] = rp[(size_t)q * rs];
+            const float2 v = rp[tg_min(q, tg_max(ntv - 1, 0)) * 16];  // always a mapped address
+            r[tt] = (tt < GK && q < ntv) ? v : make_float2(TG_NEG_BIG, 0.f);
         }
     };
     auto group_max = [&](const float2 (&r)[8]) {
@@ -499,45 +649,56 @@ __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
         for (int tt = 1; tt < 8; ++tt) m = __builtin_fmaxf(m, r[tt].x);
         return m;
     };
-    float mg[kMaxNG], cg[kMaxNG];
-    float ms = TG_NEG_BIG;
-#pragma unroll
-    for (int gq = 0; gq < kMaxNG; ++gq) {
-        mg[gq] = TG_NEG_BIG;
-        cg[gq] = 0.f;
-        if (gq < ngv) {
-            float2 r[8];
-            load_group(gq, r);
-            const float m = group_max(r);
-            float c = 0.f;
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) c += r[tt].y * __builtin_amdgcn_exp2f(r[tt].x - m);
-            mg[gq] = m;
-            cg[gq] = c;
-            ms = __builtin_fmaxf(ms, m);
-        }
-    }
-    mbuf[sp][ln] = ms;
-    __syncthreads();
-    float M = mbuf[0][ln];
-#pragma unroll
-    for (int s = 1; s < 8; ++s) M = __builtin_fmaxf(M, mbuf[s][ln]);
-    double cq[kMaxNG];
-    double ssum = 0.0;
-#pragma unroll
-    for (int gq = 0; gq < kMaxNG; ++gq) {
-        cq[gq] = 0.0;
-        if (gq < ngv) {
-            cq[gq] = (double)cg[gq] * exp2((double)mg[gq] - (double)M);
-            ssum += cq[gq];
-        }
-    }
-    sbuf[sp][ln] = ssum;
-    __syncthreads();
+    // ---- scan
+    float mgk[8], cgk[8];
     {
+        const int sp = sg >> 2, gp = sg & 3;
+        const int ntv = span_tiles(sp);
+        const float2* rp = a.rec + rec_index(rowc, sp * NT, a.ntiles);
+        float mloc = TG_NEG_BIG;
+#pragma unroll
+        for (int bt = 0; bt < 2; ++bt) {
+            float2 r[4][8];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) load_group(rp, ntv, gp * 8 + bt * 4 + k, r[k]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float m = group_max(r[k]);
+                float c = 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 8; ++tt) c += r[k][tt].y * __builtin_amdgcn_exp2f(r[k][tt].x - m);
+                mgk[bt * 4 + k] = m;
+                cgk[bt * 4 + k] = c;
+                mloc = __builtin_fmaxf(mloc, m);
+            }
+        }
+        mxb[r16][sg] = mloc;
+    }
+    __syncthreads();
+    float M = mxb[r16][0];
+#pragma unroll
+    for (int i = 1; i < 32; ++i) M = __builtin_fmaxf(M, mxb[r16][i]);
+    {
+        const int sp = sg >> 2, gp = sg & 3;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)  // groups past the span's end have sum 0
+            cqb[r16][sp][gp * 8 + k] = (double)cgk[k] * exp2((double)mgk[k] - (double)M);
+    }
+    __syncthreads();
+    // ---- select
+    const int sp = sg;  // threads tid < 128: (row r16, span sg)
+    const int ntv = tid < 128 ? span_tiles(sp) : 0;
+    const int ngv = (ntv + GK - 1) / GK;
+    if (tid < 128) {
+        double ssum = 0.0;
+        for (int gq = 0; gq < ngv; ++gq) ssum += cqb[r16][sp][gq];
+        sbuf[sp][r16] = ssum;
+    }
+    __syncthreads();
+    if (tid < 128) {
         double S = 0.0;
 #pragma unroll
-        for (int s = 0; s < 8; ++s) S += sbuf[s][ln];
+        for (int s = 0; s < 8; ++s) S += sbuf[s][r16];
         size_t orow, uidx;
         map_row(a.map, rowc, a.t, orow, uidx);
         const double target = (double)a.uniforms[uidx] * S;
@@ -545,27 +706,24 @@ __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
         int sel = last_span;
         double p = 0.0;
         for (int s = 0; s < 8; ++s) {
-            const double ss = sbuf[s][ln];
+            const double ss = sbuf[s][r16];
             if (p + ss > target || s == last_span) { sel = s; break; }
             p += ss;
         }
         if (sel == sp) {
             int gsel = ngv - 1;
-            bool found = false;
-#pragma unroll
-            for (int gq = 0; gq < kMaxNG; ++gq) {
-                if (gq < ngv && !found) {
-                    if (p + cq[gq] > target || gq == ngv - 1) { gsel = gq; found = true; }
-                    else p += cq[gq];
-                }
+            for (int gq = 0; gq < ngv; ++gq) {
+                const double c = cqb[r16][sp][gq];
+                if (p + c > target || gq == ngv - 1) { gsel = gq; break; }
+                p += c;
             }
             float2 r[8];
-            load_group(gsel, r);
-            const float m = group_max(r);  // the same value as mg[gsel]
+            load_group(a.rec + rec_index(rowc, sp * NT, a.ntiles), ntv, gsel, r);
+            const float m = group_max(r);  // the value the scan used for this group
             const double fac = exp2((double)m - (double)M);
             const int ntg = tg_min(GK, ntv - gsel * GK);
             int tsel = ntg - 1;
-            found = false;
+            bool found = false;
 #pragma unroll
             for (int tt = 0; tt < 8; ++tt) {
                 if (tt < ntg && !found) {
@@ -574,20 +732,20 @@ __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
                     else p += ts;
                 }
             }
-            selT[ln] = sp * NT + gsel * GK + tsel;
-            selp[ln] = p;
-            tgt[ln] = target;
-            Mrow[ln] = M;
+            selT[r16] = sp * NT + gsel * GK + tsel;
+            selp[r16] = p;
+            tgt[r16] = target;
+            Mrow[r16] = M;
         }
     }
     __syncthreads();
-    // the chosen tile's 16 logits again, fp32: thread (row, c) takes the 16-B column slices c, c+8, .. of every weight
-    // row (the 8 threads of a row read each 128 B of it as one line) against h = (hi + lo) / 2^13, the very operand
-    // of the first pass; partial dots summed across the 8 lanes
+    // ---- the chosen tile's 16 logits again, fp32: thread (row, eq, c) takes entries 4eq..4eq+3 and the 16-B column
+    // slices c, c+8, .. of their weight rows (the 8 threads of an entry group read each 128 B of a row as one line)
+    // against h = (hi + lo) / 2^13, the very operand of the first pass; partial dots summed across the 8 lanes
     {
-        const int rr = tid >> 3, c = tid & 7;
-        const int rrow = tg_min(blockIdx.x * 64 + rr, a.A - 1);
-        const int v0 = selT[rr] * 16;
+        const int rr = tid >> 5, eq = (tid >> 3) & 3, c = tid & 7;
+        const int rrow = tg_min(blockIdx.x * kDrawRows + rr, a.A - 1);
+        const int v0 = selT[rr] * 16 + 4 * eq;
         const float Mr = Mrow[rr];
         const int H = a.g.H, KBh = a.g.KBh;
         const int rb = rrow >> 5, j = rrow & 31;
@@ -597,61 +755,58 @@ __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
             const int y = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), C, 0xf, 0xf, true);
             return x + __builtin_bit_cast(float, y);
         };
+        float part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+        for (int ks = 0; ks < (H >> 5); ++ks) {
+            const int k0 = 32 * ks + 4 * c;
+            const size_t piece = ((size_t)(rb * KBh + (k0 >> 4)) * 2) * 64 + ((k0 >> 3) & 1) * 32 + j;
+            const f16x4 hi = *reinterpret_cast<const f16x4*>(hb + piece * 16 + 2 * (k0 & 7));
+            const f16x4 lo = *reinterpret_cast<const f16x4*>(hb + (piece + 64) * 16 + 2 * (k0 & 7));
+            float h4[4];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float part[8];
+            for (int e = 0; e < 4; ++e) h4[e] = ((float)hi[e] + (float)lo[e]) * (1.f / kHScale);
+            f32x4 wv[4];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) part[i] = 0.f;
-            for (int ks = 0; ks < (H >> 5); ++ks) {
-                const int k0 = 32 * ks + 4 * c;
-                const size_t piece = ((size_t)(rb * KBh + (k0 >> 4)) * 2) * 64 + ((k0 >> 3) & 1) * 32 + j;
-                const f16x4 hi = *reinterpret_cast<const f16x4*>(hb + piece * 16 + 2 * (k0 & 7));
-                const f16x4 lo = *reinterpret_cast<const f16x4*>(hb + (piece + 64) * 16 + 2 * (k0 & 7));
-                float h4[4];
+            for (int i = 0; i < 4; ++i)
+                wv[i] = *reinterpret_cast<const f32x4*>(a.w_out + (size_t)tg_min(v0 + i, V - 1) * H + k0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) h4[e] = ((float)hi[e] + (float)lo[e]) * (1.f / kHScale);
-                f32x4 wv[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i)
-                    wv[i] = *reinterpret_cast<const f32x4*>(a.w_out + (size_t)tg_min(v0 + 8 * half + i, V - 1) * H + k0);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    float p = part[i];
-                    p = __builtin_fmaf(wv[i][0], h4[0], p);
-                    p = __builtin_fmaf(wv[i][1], h4[1], p);
-                    p = __builtin_fmaf(wv[i][2], h4[2], p);
-                    p = __builtin_fmaf(wv[i][3], h4[3], p);
-                    part[i] = p;
-                }
-            }
-            float mine = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 float p = part[i];
-                p = dpp_add(p, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
-                p = dpp_add(p, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
-                p = dpp_add(p, std::integral_constant<int, 0x141>{});  // row_half_mirror
-                mine = (i == c) ? p : mine;
+                p = __builtin_fmaf(wv[i][0], h4[0], p);
+                p = __builtin_fmaf(wv[i][1], h4[1], p);
+                p = __builtin_fmaf(wv[i][2], h4[2], p);
+                p = __builtin_fmaf(wv[i][3], h4[3], p);
+                part[i] = p;
             }
-            const int e = 8 * half + c;
-            const int v = v0 + e;
+        }
+        float mine = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float p = part[i];
+            p = dpp_add(p, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+            p = dpp_add(p, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+            p = dpp_add(p, std::integral_constant<int, 0x141>{});  // row_half_mirror
+            mine = (i == c) ? p : mine;
+        }
+        if (c < 4) {
+            const int v = v0 + c;
             float wgt = 0.f;
             if (v < V) wgt = __builtin_amdgcn_exp2f(__builtin_fmaf(mine, kL2E, a.bias2[v]) - Mr);
-            wbuf[rr][e] = wgt;
+            wbuf[rr][4 * eq + c] = wgt;
         }
     }
     __syncthreads();
-    if (tid < 64) {
-        const int v0 = selT[ln] * 16;
+    if (tid < kDrawRows) {
+        const int v0 = selT[r16] * 16;
         const int t_hi = tg_min(V, v0 + 16);
-        const double target = tgt[ln];
-        const double p = selp[ln];
+        const double target = tgt[r16];
+        const double p = selp[r16];
         int drawn = t_hi - 1;
         float pp = 0.f;
         bool hit = false;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            pp += wbuf[ln][r];
+            pp += wbuf[r16][r];
             if (!hit && v0 + r < t_hi && p + (double)pp > target) { drawn = v0 + r; hit = true; }
         }
         if (valid) {
@@ -710,8 +865,13 @@ void launch_gemm_t(GemmArgs a, int m_blocks, int rows, hipStream_t st) {
     constexpr int bytes = 2 * (WM * TM + WN * TN) * 256 * 16;
     a.MT = m_blocks * 32 / BM;
     a.RT = (rows + BN - 1) / BN;
-    const int rtg = (a.RT + 7) / 8;
-    hipLaunchKernelGGL((k_genw_gemm<PROJ, WM, WN, TM, TN>), dim3(rtg * 8 * a.MT), dim3(64 * WM * WN), bytes, st, a);
+    a.NB = (a.RT + 7) / 8 * 8 * a.MT;
+    // TG_GENW_PERSIST=0 (diagnostic): one workgroup per tile.  Default: as many workgroups as the chip holds at once
+    // (256 CUs x workgroups per CU by LDS), each walking its share of the tiles.
+    static const char* pers = getenv("TG_GENW_PERSIST");
+    const int resident = 256 * (160 * 1024 / bytes);
+    const int grid = (pers && pers[0] == '0') ? a.NB : (a.NB < resident ? a.NB : resident);
+    hipLaunchKernelGGL((k_genw_gemm<PROJ, WM, WN, TM, TN>), dim3(grid), dim3(64 * WM * WN), bytes, st, a);
 }
 
 int prep_weights(const TgGenWeights& w, const Geom& g, const Carve& c, hipStream_t st) {
@@ -768,7 +928,7 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         a.KB = g.KBh;
         a.bias2 = c.bias2;
         a.rec = c.rec;
-        a.rowsP = rowsP;
+        a.ntiles = g.MBp * 2;
         tg_prof_begin(TG_KERNEL_GENW_PROJ, st);
         if (big_tiles(g.MBp, rows)) launch_gemm_t<true, 2, 4, 4, 2>(a, g.MBp, rows, st);
         else launch_gemm_t<true, 2, 2, 2, 2>(a, g.MBp, rows, st);
@@ -795,7 +955,7 @@ void launch_draw(const TgGenWeights& w, const Geom& g, const Carve& c, size_t ro
     d.g = g;
     d.map = map;
     d.rec = c.rec;
-    d.rowsP = rowsP;
+    d.ntiles = g.MBp * 2;
     d.A = rows;
     d.t = t;
     d.uniforms = uniforms;
@@ -806,7 +966,7 @@ void launch_draw(const TgGenWeights& w, const Geom& g, const Carve& c, size_t ro
     d.w_out = w.w_out;
     d.bias2 = c.bias2;
     tg_prof_begin(TG_KERNEL_GENW_DRAW, st);
-    hipLaunchKernelGGL(k_genw_draw, dim3((rows + 63) / 64), dim3(512), 0, st, d);
+    hipLaunchKernelGGL(k_genw_draw, dim3((rows + kDrawRows - 1) / kDrawRows), dim3(512), 0, st, d);
     tg_prof_end(st);
 }
 
@@ -846,7 +1006,7 @@ size_t tg_genw_sample_workspace_bytes(const TgGenWeights* w, int N) {
 }
 
 int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int L, int g_lo, int g_hi, int i_lo, int i_hi,
-                    const float* uniforms, const int64_t* forced, int64_t* completions, const float* states,
+                    const float* uniforms, const int64_t* forced, int64_t* completions, float* states,
                     void* workspace, size_t workspace_bytes, hipStream_t st) {
     const Geom g = make_geom(*w);
     int rc = check_shape(*w, g);
@@ -861,6 +1021,22 @@ int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int 
     if ((rc = ensure_lds())) return rc;
     if ((rc = prep_weights(*w, g, c, st))) return rc;
     const int g_hs = g_hi < L - 1 ? g_hi : L - 1;  // given_num = L only copies
+    if (g_hs >= g_lo) {
+        // states[t] = (h, c) of every sentence after its first t tokens, t = 1..g_hs, with the same cell GEMM
+        const size_t n = (size_t)B * (g.H / 4);
+        hipLaunchKernelGGL(k_genw_enter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)nullptr, 1, g.H,
+                           g.KBh, 0, B, c.hfrag[0], c.cfrag);
+        int p = 0;
+        for (int t = 1; t <= g_hs; ++t) {
+            hipLaunchKernelGGL(k_genw_tok_col, dim3((B + 255) / 256), dim3(256), 0, st, sentences, B, L, t - 1, g.V, c.tok);
+            launch_gemm(false, *w, g, c, rowsP, B, p, 1 - p, st);
+            p = 1 - p;
+            if (t >= g_lo)
+                hipLaunchKernelGGL(k_genw_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c.hfrag[p], c.cfrag,
+                                   B, g.H, g.KBh, states + (size_t)t * B * 2 * g.H);
+        }
+        GW_CHECK_LAUNCH("k_genw prefix chain");
+    }
     for (int ic = i_lo; ic < i_hi; ic += nIc) {
         const int nI = (i_hi - ic) < nIc ? (i_hi - ic) : nIc;
         const int nIB = nI * B;
@@ -901,6 +1077,59 @@ int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int 
         GW_CHECK_LAUNCH("k_genw rollout step");
     }
     GW_CHECK_LAUNCH("k_genw rollout");
+    return TG_OK;
+}
+
+size_t tg_genw_nll_workspace_bytes(const TgGenWeights* w, int N) { return tg_genw_sample_workspace_bytes(w, N); }
+
+// Teacher-forced pass for NLL.cal_nll (metrics/nll.py:49-63): zero state, inp[:, t] fed at step t, log-probability of
+// target[:, t].  Same GEMMs as the sampling paths, k_genw_lse in place of the draw.
+int tg_genw_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L, float* logp_out,
+                float* lse_out, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const Geom g = make_geom(*w);
+    int rc = check_shape(*w, g);
+    if (rc) return rc;
+    const size_t rows_c = (size_t)N < (size_t)kChunkRows ? (size_t)N : (size_t)kChunkRows;
+    const size_t rowsP = pad128(rows_c);
+    const Carve c = carve(g, rowsP, workspace);
+    if (!workspace || workspace_bytes < c.bytes) {
+        tg_set_error("wide generator path: workspace too small (%zu < %zu)", workspace_bytes, c.bytes);
+        return TG_ERR_WORKSPACE;
+    }
+    if ((rc = ensure_lds())) return rc;
+    if ((rc = prep_weights(*w, g, c, st))) return rc;
+    for (size_t n0 = 0; n0 < (size_t)N; n0 += rows_c) {
+        const int rows = (int)(((size_t)N - n0) < rows_c ? ((size_t)N - n0) : rows_c);
+        hipLaunchKernelGGL(k_genw_fill_tok, dim3((unsigned)((rowsP + 255) / 256)), dim3(256), 0, st, c.tok, rowsP, 0);
+        const size_t n = (size_t)rows * (g.H / 4);
+        hipLaunchKernelGGL(k_genw_enter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)nullptr, 1, g.H,
+                           g.KBh, 0, rows, c.hfrag[0], c.cfrag);
+        int p = 0;
+        for (int t = 0; t < L; ++t) {
+            hipLaunchKernelGGL(k_genw_tok_col, dim3((rows + 255) / 256), dim3(256), 0, st, inp + n0 * L, rows, L, t, g.V,
+                               c.tok);
+            launch_gemm(false, *w, g, c, rowsP, rows, p, 1 - p, st);
+            launch_gemm(true, *w, g, c, rowsP, rows, 1 - p, 0, st);
+            LseArgs a = {};
+            a.g = g;
+            a.rec = c.rec;
+            a.ntiles = g.MBp * 2;
+            a.rows = rows;
+            a.t = t;
+            a.L = L;
+            a.target = target + n0 * L;
+            a.logp = logp_out + n0 * L;
+            a.lse = lse_out ? lse_out + n0 * L : nullptr;
+            a.hfrag = c.hfrag[1 - p];
+            a.w_out = w->w_out;
+            a.b_out = w->b_out;
+            tg_prof_begin(TG_KERNEL_GENW_DRAW, st);
+            hipLaunchKernelGGL(k_genw_lse, dim3((rows + kDrawRows - 1) / kDrawRows), dim3(512), 0, st, a);
+            tg_prof_end(st);
+            p = 1 - p;
+        }
+        GW_CHECK_LAUNCH("k_genw nll step");
+    }
     return TG_OK;
 }
 

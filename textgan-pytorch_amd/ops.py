@@ -46,7 +46,7 @@ def gen_nll(gen, inp, target, precision=None, want_lse=False):
     dev = inp.device
     logp = torch.empty(N, L, dtype=F32, device=dev)
     lse = torch.empty(N, L, dtype=F32, device=dev) if want_lse else None
-    nbytes = _lib.lib().tg_gen_nll_workspace_bytes(C.byref(w))
+    nbytes = _lib.lib().tg_gen_nll_workspace_bytes(C.byref(w), N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     _lib.check(_lib.lib().tg_gen_nll(
         C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(target, I64, "target"), N, L,
