@@ -10,3 +10,6 @@ timeout -s KILL 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format cs
 timeout -s KILL 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -o p -- $B > /dev/null 2> $O/pmc_write.err
 echo rc=$?
 ls -R $O | head -40
+# full-size configs[2] on this one GPU (rollout_num 64, ~40 s per call)
+timeout -k 10 400 python3 bench.py --workload c3 --steps 1 --warmup 0 --no-cpu-baseline > $O/bench_c3_full.json 2> $O/bench_c3_full.err
+echo rc_full=$?
