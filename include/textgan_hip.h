@@ -289,6 +289,15 @@ int tg_reward_reduce(const float* raw, int B, int L, int R, float* out,
                      void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Exchange of the raw reward rows between ranks (the reference is single-process and has no
+ * counterpart: its rewards tensor, utils/rollout.py:138-149, is filled by one process).  Rank r has written rows
+ * [r*rows_per_rank, (r+1)*rows_per_rank) of raw [world*rows_per_rank, B]; after the call (in stream order) every
+ * rank holds all rows: one in-place ncclAllGather over xGMI on `rccl_comm` (an ncclComm_t owned by the caller).
+ * RCCL is not linked into this library: the symbols are resolved from the RCCL copy the calling process has loaded.
+ * The Python shim does the same exchange with torch.distributed.all_gather_into_tensor (dist.py). */
+int tg_allgather_rows(float* raw, size_t rows_per_rank, size_t B, void* rccl_comm, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Measurement hook (no counterpart in the reference): when enabled, every
  * kernel launch is bracketed by hipEvents on its launch stream.
  * tg_profile_read() synchronises on the recorded events of one kernel id,

@@ -90,3 +90,13 @@ def test_wide_generator_workspace_is_bounded_by_the_chunk():
     assert ws(32000, 512, 512, 4096, 51, 64, "fp32") < 1 << 30   # persistent kernel: prefix states only
     assert ws(3000, 64, 128, 8, 20, 2, "split_f16") < ws(3000, 64, 128, 8, 20, 200, "split_f16") \
         <= ws(3000, 64, 128, 8, 20, 100000, "split_f16") < 2 << 30
+
+
+def test_allgather_rows_rejects_what_it_cannot_do():
+    """tg_allgather_rows needs a caller-owned RCCL communicator; without one (or without RCCL in the process) it
+    reports an error instead of touching memory."""
+    lib = tg._lib.lib()
+    assert lib.tg_allgather_rows(None, 4, 8, None, None) == -1
+    assert b"bad arguments" in lib.tg_last_error()
+    buf = (ctypes.c_float * 64)()
+    assert lib.tg_allgather_rows(buf, 0, 8, ctypes.c_void_p(1), None) == -1

@@ -18,7 +18,7 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_dis_workspace_bytes",
            "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
            "tg_gen_nll_workspace_bytes", "tg_gen_nll", "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
-           "tg_reward_reduce",
+           "tg_reward_reduce", "tg_allgather_rows",
            "tg_profile_enable", "tg_profile_read"]
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
@@ -90,6 +90,8 @@ def lib():
         l.tg_gen_nll.restype = C.c_int
         l.tg_gen_pg_forward.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4
         l.tg_gen_pg_forward.restype = C.c_int
+        l.tg_allgather_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+        l.tg_allgather_rows.restype = C.c_int
         l.tg_profile_enable.argtypes = [C.c_int]
         l.tg_profile_enable.restype = None
         l.tg_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_int)]

@@ -1,4 +1,5 @@
 // Library plumbing (version, per-thread error string) and the reward reduce kernel.
+#include <dlfcn.h>
 #include <stdarg.h>
 #include <stdio.h>
 
@@ -98,6 +99,39 @@ extern "C" int tg_reward_reduce(const float* raw, int B, int L, int R, float* ou
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         tg_set_error("k_reward_reduce launch: %s", hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    return TG_OK;
+}
+
+// ---- the one exchange of the path, for hosts that own an RCCL communicator themselves (C++ trainers; the Python
+// shim uses torch.distributed's all_gather_into_tensor on its own process group instead, dist.py).  RCCL is not linked:
+// ncclAllGather / ncclCommUserRank are taken from the copy of the library the process has already loaded (the one
+// that created `comm`), so a communicator is never handed to a second copy.
+extern "C" int tg_allgather_rows(float* raw, size_t rows_per_rank, size_t B, void* rccl_comm, void* stream) {
+    if (!raw || !rccl_comm || rows_per_rank == 0 || B == 0) {
+        tg_set_error("tg_allgather_rows: bad arguments (raw=%p comm=%p rows_per_rank=%zu B=%zu)", (void*)raw, rccl_comm,
+                     rows_per_rank, B);
+        return TG_ERR_ARG;
+    }
+    typedef int (*rank_fn)(void*, int*);
+    typedef int (*gather_fn)(const void*, void*, size_t, int, void*, void*);
+    static rank_fn f_rank = reinterpret_cast<rank_fn>(dlsym(RTLD_DEFAULT, "ncclCommUserRank"));
+    static gather_fn f_gather = reinterpret_cast<gather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+    if (!f_rank || !f_gather) {
+        tg_set_error("tg_allgather_rows: no RCCL in this process (ncclAllGather not found)");
+        return TG_ERR_LAUNCH;
+    }
+    int rank = -1;
+    if (f_rank(rccl_comm, &rank) != 0 || rank < 0) {
+        tg_set_error("tg_allgather_rows: ncclCommUserRank failed");
+        return TG_ERR_LAUNCH;
+    }
+    const size_t count = rows_per_rank * B;
+    const int kNcclFloat = 7;  // ncclFloat32 (rccl.h ncclDataType_t)
+    const int rc = f_gather(raw + (size_t)rank * count, raw, count, kNcclFloat, rccl_comm, stream);  // in place
+    if (rc != 0) {
+        tg_set_error("tg_allgather_rows: ncclAllGather returned %d", rc);
         return TG_ERR_LAUNCH;
     }
     return TG_OK;

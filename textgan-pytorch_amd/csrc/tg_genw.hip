@@ -267,7 +267,14 @@ struct GemmArgs {
 //   <2,2,2,2>  128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU   (small problems, 4H = 128)
 //   <2,4,4,2>  256 x 256, 512 threads, 128 KiB LDS, one workgroup per CU: half the operand bytes per flop -- at
 //              128 x 128 every CU pulls ~42 B/clk from L2, which bounds the kernel before the matrix pipes do
-template <bool PROJ, int WM, int WN, int TM, int TN>
+// GLDS: stages go global -> LDS directly (global_load_lds_dwordx4: the image is lane-linear, so the DMA's
+// "wave base + 16 * lane" destination is exactly the piece order) instead of through registers.
+__device__ __forceinline__ void glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <bool PROJ, int WM, int WN, int TM, int TN, bool GLDS = false>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_genw_gemm(const GemmArgs a) {
     constexpr int NTHR = 64 * WM * WN;
@@ -316,33 +323,46 @@ void k_genw_gemm(const GemmArgs a) {
         }
     };
     load_tok(rb0, tokr);
-    f32x4 pa[NLA], pb[NLB];
-    auto load_stage = [&](int mb, int rb, const int (&tk)[NLB], int s) {
+    f32x4 pa[GLDS ? 1 : NLA], pb[GLDS ? 1 : NLB];
+    auto load_stage = [&](int mb, int rb, const int (&tk)[NLB], int s, int buf) {
+        f32x4* d = lds + buf * STAGE + tid;
 #pragma unroll
-        for (int i = 0; i < NLA; ++i)
-            pa[i] = a.A[((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw];
+        for (int i = 0; i < NLA; ++i) {
+            const f32x4* g = a.A + ((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw;
+            if constexpr (GLDS) glds16(g, d + i * NTHR);
+            else pa[i] = *g;
+        }
         if (PROJ || s >= Se) {
             const int sh = s - Se;
 #pragma unroll
-            for (int i = 0; i < NLB; ++i)
-                pb[i] = a.Bh[((size_t)(rb + ((tid + i * NTHR) >> 8)) * a.KBh + 2 * sh) * 128 + pw];
+            for (int i = 0; i < NLB; ++i) {
+                const f32x4* g = a.Bh + ((size_t)(rb + ((tid + i * NTHR) >> 8)) * a.KBh + 2 * sh) * 128 + pw;
+                if constexpr (GLDS) glds16(g, d + MBT * 256 + i * NTHR);
+                else pb[i] = *g;
+            }
         } else {
             const _Float16* tab = ((pw >> 6) & 1) ? a.emb_lo : a.emb_hi;
             const int k = (2 * s + (pw >> 7)) * 16 + 8 * ((pw >> 5) & 1);
 #pragma unroll
-            for (int i = 0; i < NLB; ++i) pb[i] = *reinterpret_cast<const f32x4*>(tab + (size_t)tk[i] * a.E + k);
+            for (int i = 0; i < NLB; ++i) {
+                const f32x4* g = reinterpret_cast<const f32x4*>(tab + (size_t)tk[i] * a.E + k);
+                if constexpr (GLDS) glds16(g, d + MBT * 256 + i * NTHR);
+                else pb[i] = *g;
+            }
         }
     };
     auto store_stage = [&](int buf) {
-        f32x4* d = lds + buf * STAGE + tid;
+        if constexpr (!GLDS) {
+            f32x4* d = lds + buf * STAGE + tid;
 #pragma unroll
-        for (int i = 0; i < NLA; ++i) d[i * NTHR] = pa[i];
+            for (int i = 0; i < NLA; ++i) d[i * NTHR] = pa[i];
 #pragma unroll
-        for (int i = 0; i < NLB; ++i) d[MBT * 256 + i * NTHR] = pb[i];
+            for (int i = 0; i < NLB; ++i) d[MBT * 256 + i * NTHR] = pb[i];
+        }
     };
     f32x16 acc[TM][TN];
 
-    load_stage(mb0, rb0, tokr, 0);
+    load_stage(mb0, rb0, tokr, 0, 0);
     store_stage(0);
     __syncthreads();
     int gs = 0;  // stages done by this workgroup: buffer parity
@@ -359,8 +379,8 @@ void k_genw_gemm(const GemmArgs a) {
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     for (int s = 0; s < S; ++s, ++gs) {
         const bool more = s + 1 < S || has_next;
-        if (s + 1 < S) load_stage(mb0, rb0, tokr, s + 1);
-        else if (has_next) load_stage(nmb0, nrb0, tokn, 0);
+        if (s + 1 < S) load_stage(mb0, rb0, tokr, s + 1, (gs + 1) & 1);
+        else if (has_next) load_stage(nmb0, nrb0, tokn, 0, (gs + 1) & 1);
         const f32x4* la = lds + (gs & 1) * STAGE + (TM * wm) * 256 + lane;
         const f32x4* lbp = lds + (gs & 1) * STAGE + MBT * 256 + (TN * wn) * 256 + lane;
 #pragma unroll
@@ -835,10 +855,10 @@ __global__ __launch_bounds__(256) void k_genw_fill_tok(int* tok, size_t n, int v
         }                                                                  \
     } while (0)
 
-template <bool PROJ, int WM, int WN, int TM, int TN>
+template <bool PROJ, int WM, int WN, int TM, int TN, bool GLDS = false>
 int gemm_lds_attr() {
     constexpr int bytes = 2 * (WM * TM + WN * TN) * 256 * 16;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<PROJ, WM, WN, TM, TN>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_genw_gemm<PROJ, WM, WN, TM, TN, GLDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
     if (e != hipSuccess) {
         tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -854,12 +874,14 @@ int ensure_lds() {
     if (!rc) rc = gemm_lds_attr<false, 2, 2, 2, 2>();
     if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2>();
     if (!rc) rc = gemm_lds_attr<false, 2, 4, 4, 2>();
+    if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2, true>();
+    if (!rc) rc = gemm_lds_attr<false, 2, 4, 4, 2, true>();
     if (rc) return rc;
     done = true;
     return TG_OK;
 }
 
-template <bool PROJ, int WM, int WN, int TM, int TN>
+template <bool PROJ, int WM, int WN, int TM, int TN, bool GLDS = false>
 void launch_gemm_t(GemmArgs a, int m_blocks, int rows, hipStream_t st) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr int bytes = 2 * (WM * TM + WN * TN) * 256 * 16;
@@ -871,7 +893,7 @@ void launch_gemm_t(GemmArgs a, int m_blocks, int rows, hipStream_t st) {
     static const char* pers = getenv("TG_GENW_PERSIST");
     const int resident = 256 * (160 * 1024 / bytes);
     const int grid = (pers && pers[0] == '0') ? a.NB : (a.NB < resident ? a.NB : resident);
-    hipLaunchKernelGGL((k_genw_gemm<PROJ, WM, WN, TM, TN>), dim3(grid), dim3(64 * WM * WN), bytes, st, a);
+    hipLaunchKernelGGL((k_genw_gemm<PROJ, WM, WN, TM, TN, GLDS>), dim3(grid), dim3(64 * WM * WN), bytes, st, a);
 }
 
 int prep_weights(const TgGenWeights& w, const Geom& g, const Carve& c, hipStream_t st) {
@@ -913,6 +935,11 @@ bool big_tiles(int m_blocks, int rows) {
     return (long)(m_blocks / 8) * ((rows + 255) / 256) >= 256;
 }
 
+bool use_glds() {
+    static const char* e = getenv("TG_GENW_GLDS");  // diagnostic: "0" = register staging in the 256 x 256 GEMMs
+    return !(e && e[0] == '0');
+}
+
 void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
                  int hdst, hipStream_t st) {
     GemmArgs a = {};
@@ -930,7 +957,8 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         a.rec = c.rec;
         a.ntiles = g.MBp * 2;
         tg_prof_begin(TG_KERNEL_GENW_PROJ, st);
-        if (big_tiles(g.MBp, rows)) launch_gemm_t<true, 2, 4, 4, 2>(a, g.MBp, rows, st);
+        if (big_tiles(g.MBp, rows) && use_glds()) launch_gemm_t<true, 2, 4, 4, 2, true>(a, g.MBp, rows, st);
+        else if (big_tiles(g.MBp, rows)) launch_gemm_t<true, 2, 4, 4, 2>(a, g.MBp, rows, st);
         else launch_gemm_t<true, 2, 2, 2, 2>(a, g.MBp, rows, st);
         tg_prof_end(st);
     } else {
@@ -943,7 +971,8 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         a.cfrag = c.cfrag;
         a.hdst = c.hfrag[hdst];
         tg_prof_begin(TG_KERNEL_GENW_CELL, st);
-        if (big_tiles(4 * g.H / 32, rows)) launch_gemm_t<false, 2, 4, 4, 2>(a, 4 * g.H / 32, rows, st);
+        if (big_tiles(4 * g.H / 32, rows) && use_glds()) launch_gemm_t<false, 2, 4, 4, 2, true>(a, 4 * g.H / 32, rows, st);
+        else if (big_tiles(4 * g.H / 32, rows)) launch_gemm_t<false, 2, 4, 4, 2>(a, 4 * g.H / 32, rows, st);
         else launch_gemm_t<false, 2, 2, 2, 2>(a, 4 * g.H / 32, rows, st);
         tg_prof_end(st);
     }
