@@ -267,6 +267,79 @@ struct GemmArgs {
 //   <2,2,2,2>  128 x 128, 256 threads, 64 KiB LDS, two workgroups per CU   (small problems, 4H = 128)
 //   <2,4,4,2>  256 x 256, 512 threads, 128 KiB LDS, one workgroup per CU: half the operand bytes per flop -- at
 //              128 x 128 every CU pulls ~42 B/clk from L2, which bounds the kernel before the matrix pipes do
+// PROJ epilogue of one wave: accumulators acc[mi][ni] = tile rows (vocabulary blocks mbw + mi) x completion blocks rbw + ni
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_proj(const GemmArgs& a, const f32x16 (&acc)[TM][TN], int mbw, int rbw, int n, int hh) {
+    // per (row, 16-entry tile): m = max logit (base 2), s = sum 2^(l - m) in entry order
+    const float inv = a.sc->invProj;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int mb = mbw + mi;
+        float bias[16];
+        const f32x4* pbias = reinterpret_cast<const f32x4*>(a.bias2 + 32 * mb + 16 * hh);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const f32x4 b4 = pbias[q4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias[4 * q4 + e] = b4[e];
+        }
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int row = (rbw + ni) * 32 + n;
+            float l[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) l[r] = __builtin_fmaf(acc[mi][ni][r], inv, bias[r]);
+            float m = l[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, l[r]);
+            float ev[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(l[r] - m);
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += ev[r];
+            // streamed once, read once by the draw kernel: keep it out of the L2 the operand tiles live in
+            __builtin_nontemporal_store(__builtin_bit_cast(double, make_float2(m, s)),
+                                        reinterpret_cast<double*>(a.rec + rec_index(row, 2 * mb + hh, a.ntiles)));
+        }
+    }
+}
+
+// CELL epilogue of one wave: gate tiles mbw + mi (8 hidden units each) x completion blocks rbw + ni
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_cell(const GemmArgs& a, const f32x16 (&acc)[TM][TN], int mbw, int rbw, int n, int hh,
+                                              int lane) {
+    const float inv = a.sc->invCell;
+    const int H = a.H;
+#pragma unroll
+    for (int mi = 0; mi < TM; ++mi) {
+        const int T = mbw + mi;
+        const int u0 = 8 * T + 4 * hh;
+        f32x4 gbias[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gbias[q] = *reinterpret_cast<const f32x4*>(a.gb + q * H + u0);
+#pragma unroll
+        for (int ni = 0; ni < TN; ++ni) {
+            const int rb = rbw + ni;
+            f32x4* cp = a.cfrag + ((size_t)rb * (H >> 3) + T) * 64 + lane;
+            const f32x4 c_old = *cp;
+            f32x4 c_new, h_new;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ig = tg_sigmoid(__builtin_fmaf(acc[mi][ni][e], inv, gbias[0][e]));
+                const float fg = tg_sigmoid(__builtin_fmaf(acc[mi][ni][4 + e], inv, gbias[1][e]));
+                const float gg = tg_tanh(__builtin_fmaf(acc[mi][ni][8 + e], inv, gbias[2][e]));
+                const float og = tg_sigmoid(__builtin_fmaf(acc[mi][ni][12 + e], inv, gbias[3][e]));
+                const float cn = fg * c_old[e] + ig * gg;
+                c_new[e] = cn;
+                h_new[e] = og * tg_tanh(cn);
+            }
+            *cp = c_new;
+            store_h4(a.hdst, a.KBh, rb * 32 + n, T, hh, h_new);
+        }
+    }
+}
+
 // GLDS: stages go global -> LDS directly (global_load_lds_dwordx4: the image is lane-linear, so the DMA's
 // "wave base + 16 * lane" destination is exactly the piece order) instead of through registers.
 __device__ __forceinline__ void glds16(const void* g, void* l) {
@@ -416,71 +489,8 @@ void k_genw_gemm(const GemmArgs a) {
         __syncthreads();
     }
 
-    if constexpr (PROJ) {
-        // per (row, 16-entry tile): m = max logit (base 2), s = sum 2^(l - m) in entry order
-        const float inv = a.sc->invProj;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int mb = mb0 + TM * wm + mi;
-            float bias[16];
-            const f32x4* pbias = reinterpret_cast<const f32x4*>(a.bias2 + 32 * mb + 16 * hh);
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const f32x4 b4 = pbias[q4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) bias[4 * q4 + e] = b4[e];
-            }
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int row = (rb0 + TN * wn + ni) * 32 + n;
-                float l[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) l[r] = __builtin_fmaf(acc[mi][ni][r], inv, bias[r]);
-                float m = l[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) m = __builtin_fmaxf(m, l[r]);
-                float ev[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(l[r] - m);
-                float s = 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) s += ev[r];
-                // streamed once, read once by the draw kernel: keep it out of the L2 the operand tiles live in
-                __builtin_nontemporal_store(__builtin_bit_cast(double, make_float2(m, s)),
-                                            reinterpret_cast<double*>(a.rec + rec_index(row, 2 * mb + hh, a.ntiles)));
-            }
-        }
-    } else {
-        const float inv = a.sc->invCell;
-        const int H = a.H;
-#pragma unroll
-        for (int mi = 0; mi < TM; ++mi) {
-            const int T = mb0 + TM * wm + mi;
-            const int u0 = 8 * T + 4 * hh;
-            f32x4 gbias[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) gbias[q] = *reinterpret_cast<const f32x4*>(a.gb + q * H + u0);
-#pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
-                const int rb = rb0 + TN * wn + ni;
-                f32x4* cp = a.cfrag + ((size_t)rb * (H >> 3) + T) * 64 + lane;
-                const f32x4 c_old = *cp;
-                f32x4 c_new, h_new;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float ig = tg_sigmoid(__builtin_fmaf(acc[mi][ni][e], inv, gbias[0][e]));
-                    const float fg = tg_sigmoid(__builtin_fmaf(acc[mi][ni][4 + e], inv, gbias[1][e]));
-                    const float gg = tg_tanh(__builtin_fmaf(acc[mi][ni][8 + e], inv, gbias[2][e]));
-                    const float og = tg_sigmoid(__builtin_fmaf(acc[mi][ni][12 + e], inv, gbias[3][e]));
-                    const float cn = fg * c_old[e] + ig * gg;
-                    c_new[e] = cn;
-                    h_new[e] = og * tg_tanh(cn);
-                }
-                *cp = c_new;
-                store_h4(a.hdst, a.KBh, rb * 32 + n, T, hh, h_new);
-            }
-        }
-    }
+    if constexpr (PROJ) epilogue_proj<TM, TN>(a, acc, mb0 + TM * wm, rb0 + TN * wn, n, hh);
+    else epilogue_cell<TM, TN>(a, acc, mb0 + TM * wm, rb0 + TN * wn, n, hh, lane);
     if (!has_next) break;
     lb = nlb;
     mb0 = nmb0;
@@ -589,6 +599,7 @@ __global__ __launch_bounds__(256) void k_genw_export(const f32x4* __restrict__ h
     *reinterpret_cast<f32x4*>(d) = h;
     *reinterpret_cast<f32x4*>(d + H) = cfrag[((size_t)rb * (H >> 3) + T) * 64 + hh * 32 + j];
 }
+
 
 // ------------------------------------------------------------------ row <-> output mapping
 struct RowMap {
