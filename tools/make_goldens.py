@@ -223,37 +223,46 @@ def run_dis(name, V, L, N, dis_kind, dseed, sseed, k_label=4):
 
 
 def main():
+    """All cases, or only those named on the command line (python tools/make_goldens.py reward_v20k_h64)."""
     os.makedirs(OUT, exist_ok=True)
     oracle.build()
     torch.set_num_threads(8)
+    only = set(sys.argv[1:])
+
+    def case(fn, name, *a, **k):
+        if not only or name in only:
+            fn(name, *a, **k)
+
     # get_reward: tiny peaked (oracle-style N(0,1) weights), tiny flat, SentiGAN k-way with live dropout,
     # long sequences, and the C1 shape at reduced rollout_num
-    run_get_reward("reward_tiny_peaked", 200, 32, 32, 20, 8, 2, "seqgan", 11, 1.0, 12, 13, 14)
-    run_get_reward("reward_tiny_flat", 200, 32, 32, 20, 8, 3, "seqgan", 21, 0.2, 22, 23, 24)
-    run_get_reward("reward_tiny_dropout", 200, 32, 32, 20, 8, 2, "seqgan", 31, 0.3, 32, 33, 34, dropout=True)
-    run_get_reward("reward_senti_k2", 150, 32, 32, 20, 6, 2, "sentigan", 41, 0.3, 42, 43, 44,
+    case(run_get_reward, "reward_tiny_peaked", 200, 32, 32, 20, 8, 2, "seqgan", 11, 1.0, 12, 13, 14)
+    case(run_get_reward, "reward_tiny_flat", 200, 32, 32, 20, 8, 3, "seqgan", 21, 0.2, 22, 23, 24)
+    case(run_get_reward, "reward_tiny_dropout", 200, 32, 32, 20, 8, 2, "seqgan", 31, 0.3, 32, 33, 34, dropout=True)
+    case(run_get_reward, "reward_senti_k2", 150, 32, 32, 20, 6, 2, "sentigan", 41, 0.3, 42, 43, 44,
                    current_k=2, dropout=True, senti=True)
-    run_get_reward("reward_len51", 333, 32, 32, 51, 4, 2, "seqgan", 51, 0.25, 52, 53, 54)
-    run_get_reward("reward_c1_r2", 5000, 32, 32, 20, 64, 2, "seqgan", 0, 1.0, 0, 1, 2)
-    run_get_reward("reward_c2_r1", 5255, 32, 32, 51, 64, 1, "seqgan", 3, 1.0, 3, 4, 5)
-    run_get_reward("reward_c1_flat_r1", 5000, 32, 32, 20, 64, 1, "seqgan", 5, 0.1, 6, 7, 8)
+    case(run_get_reward, "reward_len51", 333, 32, 32, 51, 4, 2, "seqgan", 51, 0.25, 52, 53, 54)
+    case(run_get_reward, "reward_c1_r2", 5000, 32, 32, 20, 64, 2, "seqgan", 0, 1.0, 0, 1, 2)
+    case(run_get_reward, "reward_c2_r1", 5255, 32, 32, 51, 64, 1, "seqgan", 3, 1.0, 3, 4, 5)
+    case(run_get_reward, "reward_c1_flat_r1", 5000, 32, 32, 20, 64, 1, "seqgan", 5, 0.1, 6, 7, 8)
     # larger generators (the scaled config's E = H = 512 at small V / B, and E != H)
-    run_get_reward("reward_h64", 300, 64, 64, 20, 8, 2, "seqgan", 91, 0.3, 92, 93, 94)
-    run_get_reward("reward_e32_h128", 260, 32, 128, 20, 6, 2, "seqgan", 95, 0.15, 96, 97, 98)
-    run_get_reward("reward_e96_h32", 200, 96, 32, 20, 5, 2, "seqgan", 99, 0.3, 100, 101, 102)
-    run_get_reward("reward_h512", 1000, 512, 512, 20, 4, 1, "seqgan", 103, 0.05, 104, 105, 106)
+    case(run_get_reward, "reward_h64", 300, 64, 64, 20, 8, 2, "seqgan", 91, 0.3, 92, 93, 94)
+    case(run_get_reward, "reward_e32_h128", 260, 32, 128, 20, 6, 2, "seqgan", 95, 0.15, 96, 97, 98)
+    case(run_get_reward, "reward_e96_h32", 200, 96, 32, 20, 5, 2, "seqgan", 99, 0.3, 100, 101, 102)
+    case(run_get_reward, "reward_h512", 1000, 512, 512, 20, 4, 1, "seqgan", 103, 0.05, 104, 105, 106)
+    # a vocabulary past 16 384: the canonical sampler has more than 16 groups per span there
+    case(run_get_reward, "reward_v20k_h64", 20011, 64, 64, 20, 8, 2, "seqgan", 107, 0.3, 108, 109, 110)
     # forward / NLL
-    run_forward_nll("nll_tiny", 200, 32, 32, 20, 43, 8, 61, 1.0, 62, save_logits=True)
-    run_forward_nll("nll_c5_slice", 5000, 32, 32, 20, 200, 64, 0, 1.0, 63, save_logits=False)
-    run_forward_nll("nll_h256", 500, 256, 256, 20, 40, 8, 64, 0.08, 65, save_logits=True)
+    case(run_forward_nll, "nll_tiny", 200, 32, 32, 20, 43, 8, 61, 1.0, 62, save_logits=True)
+    case(run_forward_nll, "nll_c5_slice", 5000, 32, 32, 20, 200, 64, 0, 1.0, 63, save_logits=False)
+    case(run_forward_nll, "nll_h256", 500, 256, 256, 20, 40, 8, 64, 0.08, 65, save_logits=True)
     # sample
-    run_sample("sample_h64", 300, 64, 64, 20, 10, 4, 74, 0.3, 75)
-    run_sample("sample_tiny", 200, 32, 32, 20, 20, 8, 71, 0.3, 72)
-    run_sample("sample_eq_batch", 5000, 32, 32, 20, 64, 64, 0, 1.0, 73)
+    case(run_sample, "sample_h64", 300, 64, 64, 20, 10, 4, 74, 0.3, 75)
+    case(run_sample, "sample_tiny", 200, 32, 32, 20, 20, 8, 71, 0.3, 72)
+    case(run_sample, "sample_eq_batch", 5000, 32, 32, 20, 64, 64, 0, 1.0, 73)
     # discriminator alone
-    run_dis("dis_seqgan", 300, 20, 16, "seqgan", 81, 82)
-    run_dis("dis_seqgan_len51", 300, 51, 6, "seqgan", 83, 84)
-    run_dis("dis_senti", 300, 20, 16, "sentigan", 85, 86)
+    case(run_dis, "dis_seqgan", 300, 20, 16, "seqgan", 81, 82)
+    case(run_dis, "dis_seqgan_len51", 300, 51, 6, "seqgan", 83, 84)
+    case(run_dis, "dis_senti", 300, 20, 16, "sentigan", 85, 86)
 
 
 if __name__ == "__main__":
