@@ -485,6 +485,53 @@ def test_get_reward_c2_full_size_properties():
     assert torch.equal(rw[:, L - 1], rw[0, L - 1].expand(R, B))
 
 
+def test_wide_rollout_across_chunks_against_oracle():
+    """The GEMM path advances at most 2^18 completions together: B*L*R = 409 600 here, two chunks of rollout indices
+    (25 + 15).  Token parity with the oracle over the whole call, and the second chunk on its own equals the full call."""
+    V, E, H, B, L, R = 700, 32, 64, 512, 20, 40
+    gsd = synth.gen_state(V, E, H, seed=15, std=0.3)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    sent, u = synth.tokens(25, (B, L), V), synth.uniform01(26, (R, L, L, B))
+    ref = oracle.gen_rollout(og, sent, R, u)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision="split_f16")
+    _cases.check_token_parity(replay.cpu().numpy(), ref, u, og, max_check=20)
+    part = torch.full_like(replay, -1)
+    tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), i_lo=25, i_hi=R, out=part, precision="split_f16")
+    assert torch.equal(part[25:], replay[25:]) and bool((part[:25] == -1).all())
+
+
+def test_get_reward_scaled_shape_properties():
+    """BASELINE config 3's shape (V32000 L51 E=H=512 B4096) at rollout_num 2 -- two chunks of the GEMM path, 417 792
+    completions: determinism, prefix copies, shards by rollout index equal to the unsharded call bit for bit, rewards
+    are probabilities, the given_num = L rows do not depend on the rollout index."""
+    V, L, E, H, B, R = 32000, 51, 512, 512, 4096, 2
+    gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=0.05, device=DEV)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=DEV).eval()
+    sent = _t(synth.tokens(1, (B, L), V))
+    g = torch.Generator(device=DEV)
+    g.manual_seed(11)
+    u = torch.rand(R, L, L, B, device=DEV, generator=g)
+    ro = tg.ROLLOUT(gen)
+    rew, raw, comp = ro.get_reward(sent, R, dis, uniforms=u, return_parts=True)
+    rew2, raw2, comp2 = ro.get_reward(sent, R, dis, uniforms=u, return_parts=True)
+    assert torch.equal(comp, comp2) and torch.equal(raw, raw2) and torch.equal(rew, rew2)
+    assert tuple(comp.shape) == (R, L, B, L) and int(comp.min()) >= 0 and int(comp.max()) < V
+    for gnum in (1, 23, L):
+        assert torch.equal(comp[:, gnum - 1, :, :gnum], sent[:, :gnum].expand(R, B, gnum))
+    assert not torch.equal(comp[0, 0], comp[1, 0])  # different uniforms, different completions
+    assert bool(((raw >= 0) & (raw <= 1)).all())
+    rw = raw.view(R, L, B)
+    assert torch.equal(rw[:, L - 1], rw[0, L - 1].expand(R, B))
+    part = torch.full_like(comp, -1)
+    tg.ops.gen_rollout(gen, sent, R, u, i_lo=1, i_hi=2, out=part)
+    assert torch.equal(part[1], comp[1]) and bool((part[0] == -1).all())
+    # every sampled token is a draw from the whole vocabulary: over 5 M draws of a near-flat distribution the
+    # top and bottom halves of the id range both occur in quantity
+    drawn = comp[0, 0, :, 1:]
+    assert 0.4 < float((drawn < V // 2).float().mean()) < 0.6
+
+
 @pytest.mark.parametrize("precision", ["fp32", "split_f16"])
 @pytest.mark.parametrize("name", _cases.names("mali_reward"))
 def test_mali_reward(name, precision):
