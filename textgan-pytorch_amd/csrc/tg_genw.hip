@@ -866,6 +866,17 @@ __global__ __launch_bounds__(256) void k_genw_fill_tok(int* tok, size_t n, int v
         }                                                                  \
     } while (0)
 
+// First character of an environment switch -- in `make DIAG=1` builds only; the shipped library reads no environment.
+char diag_env(const char* name) {
+#if TG_DIAG
+    const char* e = getenv(name);
+    return e ? e[0] : 0;
+#else
+    (void)name;
+    return 0;
+#endif
+}
+
 template <bool PROJ, int WM, int WN, int TM, int TN, bool GLDS = false>
 int gemm_lds_attr() {
     constexpr int bytes = 2 * (WM * TM + WN * TN) * 256 * 16;
@@ -885,6 +896,8 @@ int ensure_lds() {
     if (!rc) rc = gemm_lds_attr<false, 2, 2, 2, 2>();
     if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2>();
     if (!rc) rc = gemm_lds_attr<false, 2, 4, 4, 2>();
+    if (!rc) rc = gemm_lds_attr<true, 2, 2, 2, 2, true>();
+    if (!rc) rc = gemm_lds_attr<false, 2, 2, 2, 2, true>();
     if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2, true>();
     if (!rc) rc = gemm_lds_attr<false, 2, 4, 4, 2, true>();
     if (rc) return rc;
@@ -899,11 +912,10 @@ void launch_gemm_t(GemmArgs a, int m_blocks, int rows, hipStream_t st) {
     a.MT = m_blocks * 32 / BM;
     a.RT = (rows + BN - 1) / BN;
     a.NB = (a.RT + 7) / 8 * 8 * a.MT;
-    // TG_GENW_PERSIST=0 (diagnostic): one workgroup per tile.  Default: as many workgroups as the chip holds at once
-    // (256 CUs x workgroups per CU by LDS), each walking its share of the tiles.
-    static const char* pers = getenv("TG_GENW_PERSIST");
+    // as many workgroups as the chip holds at once (256 CUs x workgroups per CU by LDS), each walking its share of the
+    // tiles (TG_GENW_PERSIST=0 in a DIAG build: one workgroup per tile)
     const int resident = 256 * (160 * 1024 / bytes);
-    const int grid = (pers && pers[0] == '0') ? a.NB : (a.NB < resident ? a.NB : resident);
+    const int grid = diag_env("TG_GENW_PERSIST") == '0' ? a.NB : (a.NB < resident ? a.NB : resident);
     hipLaunchKernelGGL((k_genw_gemm<PROJ, WM, WN, TM, TN, GLDS>), dim3(grid), dim3(64 * WM * WN), bytes, st, a);
 }
 
@@ -939,17 +951,14 @@ int prep_weights(const TgGenWeights& w, const Geom& g, const Carve& c, hipStream
 
 // 256 x 256 tiles once the problem fills the chip with them and M divides; 128 x 128 otherwise
 bool big_tiles(int m_blocks, int rows) {
-    static const char* force = getenv("TG_GENW_TILE");  // diagnostic override: "128" or "256"
+    const char force = diag_env("TG_GENW_TILE");  // DIAG build: "128" or "256"
     if (m_blocks % 8) return false;
-    if (force && force[0] == '1') return false;
-    if (force && force[0] == '2') return true;
+    if (force == '1') return false;
+    if (force == '2') return true;
     return (long)(m_blocks / 8) * ((rows + 255) / 256) >= 256;
 }
 
-bool use_glds() {
-    static const char* e = getenv("TG_GENW_GLDS");  // diagnostic: "0" = register staging in the 256 x 256 GEMMs
-    return !(e && e[0] == '0');
-}
+bool use_glds() { return diag_env("TG_GENW_GLDS") != '0'; }  // DIAG build: "0" = register staging in the 256 x 256 GEMMs
 
 void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
                  int hdst, hipStream_t st) {
@@ -970,6 +979,7 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         tg_prof_begin(TG_KERNEL_GENW_PROJ, st);
         if (big_tiles(g.MBp, rows) && use_glds()) launch_gemm_t<true, 2, 4, 4, 2, true>(a, g.MBp, rows, st);
         else if (big_tiles(g.MBp, rows)) launch_gemm_t<true, 2, 4, 4, 2>(a, g.MBp, rows, st);
+        else if (use_glds()) launch_gemm_t<true, 2, 2, 2, 2, true>(a, g.MBp, rows, st);
         else launch_gemm_t<true, 2, 2, 2, 2>(a, g.MBp, rows, st);
         tg_prof_end(st);
     } else {
@@ -984,6 +994,7 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         tg_prof_begin(TG_KERNEL_GENW_CELL, st);
         if (big_tiles(4 * g.H / 32, rows) && use_glds()) launch_gemm_t<false, 2, 4, 4, 2, true>(a, 4 * g.H / 32, rows, st);
         else if (big_tiles(4 * g.H / 32, rows)) launch_gemm_t<false, 2, 4, 4, 2>(a, 4 * g.H / 32, rows, st);
+        else if (use_glds()) launch_gemm_t<false, 2, 2, 2, 2, true>(a, 4 * g.H / 32, rows, st);
         else launch_gemm_t<false, 2, 2, 2, 2>(a, 4 * g.H / 32, rows, st);
         tg_prof_end(st);
     }
