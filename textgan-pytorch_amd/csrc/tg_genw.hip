@@ -470,6 +470,7 @@ void k_genw_gemm(const GemmArgs a) {
                 al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
             }
             // product-major: TM*TN independent accumulators between two MFMAs on the same one
+            __builtin_amdgcn_s_setprio(1);  // the wave that has its operands runs its MFMA block through (-1.5 % on PROJ)
 #pragma unroll
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -482,6 +483,7 @@ void k_genw_gemm(const GemmArgs a) {
             for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
+            __builtin_amdgcn_s_setprio(0);
             // the next stage goes to the other buffer (last read before the previous barrier) while the first k
             // block's MFMAs are still draining
             if (kbl == 0 && more) store_stage((gs + 1) & 1);
