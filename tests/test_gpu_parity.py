@@ -59,7 +59,7 @@ def test_teacher_forced_logits_and_nll(name):
         np.testing.assert_allclose(lp[:8], c["logprobs"], rtol=1e-5, atol=2e-5)
     # the drop-in NLL surface: a loader of dicts, and the loader-free form
     loader = [{"input": inp[i:i + batch].cpu(), "target": tgt[i:i + batch].cpu()} for i in range(0, nb, batch)]
-    for prec in ("fp32", "split_f16"):  # tg_gen_nll; split takes effect at E = H = 32, other shapes run fp32
+    for prec in ("fp32", "split_f16"):  # tg_gen_nll; split: E = H = 32 inside the persistent kernel, other shapes the GEMM path
         assert tg.nll.cal_nll(gen, loader, precision=prec) == pytest.approx(c["nll"], abs=1.01e-4)
         val, pb = tg.nll.nll_of_samples(gen, tgt, batch, start_letter=1, precision=prec)
         assert val == pytest.approx(c["nll"], abs=1.01e-4)
