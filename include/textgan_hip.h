@@ -55,7 +55,7 @@ typedef struct TgGenWeights {
  *   TG_GEN_SPLIT_F16  operands scaled by a power of two and split into fp16 hi + lo (22 mantissa bits), three
  *                     fp16 MFMAs per product with fp32 accumulation, bias added exactly; logits move by ~1e-6.
  *                     E = H = 32 (every SeqGAN / SentiGAN config of the reference): inside the persistent kernel.
- *                     Other shapes (E, H multiples of 32, V <= 32768 -- the scaled config): tg_gen_rollout and
+ *                     Other shapes (E, H multiples of 32, V <= 65536 -- the scaled config): tg_gen_rollout and
  *                     tg_gen_sample / tg_gen_nll run step-synchronous split-fp16 GEMMs for the gates and the
  *                     projection (tg_genw.hip); tg_gen_teacher_forced stays fp32 there. */
 #define TG_GEN_FP32 0

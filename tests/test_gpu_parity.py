@@ -153,6 +153,7 @@ WIDE_CASES = [
     # are ragged against the 128-wide GEMM tiles, E != H
     (20011, 64, 64, 5, 7, 3, 0.3),
     (32000, 32, 128, 8, 6, 2, 0.2),
+    (50257, 64, 64, 6, 5, 2, 0.2),     # 50 groups per span: the draw kernel's second instantiation
     (1500, 96, 32, 40, 9, 4, 0.5),
     (4099, 512, 512, 3, 5, 2, 0.05),
 ]

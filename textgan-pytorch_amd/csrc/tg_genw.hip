@@ -33,7 +33,7 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr float kHScale = 8192.f;  // h in (-1, 1) -> below 2^13 in fp16
 constexpr float kL2E = 1.44269502162933349609375f;
 constexpr int kChunkRows = 1 << 18;  // rows (completions) advanced together
-constexpr int kMaxNG = 32;           // groups per span the draw kernel handles (V <= 32768)
+constexpr int kMaxNG = 64;           // groups per span the draw kernel handles (V <= 65536)
 constexpr int kDrawRows = 16;        // rows per workgroup of the record-scanning kernels (draw, lse)
 
 struct Scales {  // device side, written by k_genw_prep
@@ -651,11 +651,13 @@ struct DrawArgs {
 // group sums (fp32, tile order) -> span sums / total / target / every prefix comparison in fp64.  Tile sums come from
 // the records at their own maximum and are moved to the group's maximum in fp32, the group sums to the row's maximum
 // in fp64.
-//   scan     thread (row, span, quarter): 8 of the span's <= 32 groups, their 64 records fetched 32 at a time
+//   scan     thread (row, span, quarter): GPT of the span's <= 4 GPT groups, their records fetched 32 at a time
+//            (GPT = 8: up to 32 groups per span, V <= 32768; GPT = 16: up to 64, V <= 65536)
 //   select   thread (row, span): span sum in group order, then the owner of the chosen span walks groups and tiles
 //   logits   32 threads per row recompute the chosen tile's 16 logits (4 entries x an eighth of k each)
+template <int GPT>
 __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
-    __shared__ double cqb[kDrawRows][8][kMaxNG];  // (max, sum) pairs of the groups, then their fp64 contributions
+    __shared__ double cqb[kDrawRows][8][4 * GPT];  // (max, sum) pairs of the groups, then their fp64 contributions
     __shared__ float mxb[kDrawRows][32];
     __shared__ double sbuf[8][kDrawRows];
     __shared__ int selT[kDrawRows];
@@ -683,17 +685,17 @@ __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
         return m;
     };
     // ---- scan
-    float mgk[8], cgk[8];
+    float mgk[GPT], cgk[GPT];
     {
         const int sp = sg >> 2, gp = sg & 3;
         const int ntv = span_tiles(sp);
         const float2* rp = a.rec + rec_index(rowc, sp * NT, a.ntiles);
         float mloc = TG_NEG_BIG;
 #pragma unroll
-        for (int bt = 0; bt < 2; ++bt) {
+        for (int bt = 0; bt < GPT / 4; ++bt) {
             float2 r[4][8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) load_group(rp, ntv, gp * 8 + bt * 4 + k, r[k]);
+            for (int k = 0; k < 4; ++k) load_group(rp, ntv, gp * GPT + bt * 4 + k, r[k]);
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float m = group_max(r[k]);
@@ -714,8 +716,8 @@ __global__ __launch_bounds__(512) void k_genw_draw(const DrawArgs a) {
     {
         const int sp = sg >> 2, gp = sg & 3;
 #pragma unroll
-        for (int k = 0; k < 8; ++k)  // groups past the span's end have sum 0
-            cqb[r16][sp][gp * 8 + k] = (double)cgk[k] * exp2((double)mgk[k] - (double)M);
+        for (int k = 0; k < GPT; ++k)  // groups past the span's end have sum 0
+            cqb[r16][sp][gp * GPT + k] = (double)cgk[k] * exp2((double)mgk[k] - (double)M);
     }
     __syncthreads();
     // ---- select
@@ -1019,13 +1021,14 @@ void launch_draw(const TgGenWeights& w, const Geom& g, const Carve& c, size_t ro
     d.w_out = w.w_out;
     d.bias2 = c.bias2;
     tg_prof_begin(TG_KERNEL_GENW_DRAW, st);
-    hipLaunchKernelGGL(k_genw_draw, dim3((rows + kDrawRows - 1) / kDrawRows), dim3(512), 0, st, d);
+    if (g.NG <= 32) hipLaunchKernelGGL(k_genw_draw<8>, dim3((rows + kDrawRows - 1) / kDrawRows), dim3(512), 0, st, d);
+    else hipLaunchKernelGGL(k_genw_draw<16>, dim3((rows + kDrawRows - 1) / kDrawRows), dim3(512), 0, st, d);
     tg_prof_end(st);
 }
 
 int check_shape(const TgGenWeights& w, const Geom& g) {
     if (w.H % 32 || w.E % 32 || g.NG > kMaxNG) {
-        tg_set_error("wide generator path: needs E, H multiples of 32 and V <= 32768 (V=%d E=%d H=%d)", w.V, w.E, w.H);
+        tg_set_error("wide generator path: needs E, H multiples of 32 and V <= 65536 (V=%d E=%d H=%d)", w.V, w.E, w.H);
         return TG_ERR_ARG;
     }
     return TG_OK;
