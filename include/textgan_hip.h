@@ -98,7 +98,9 @@ const char* tg_version(void);
 /* Last error message of the calling thread. host string. */
 const char* tg_last_error(void);
 
-/* 0 if the (V,E,H) generator shape is supported by the compiled kernels. */
+/* 0: the (V,E,H) generator shape is supported by every entry point and precision (H in {32,64,128,256,512}, E a
+ * multiple of 32 up to 512); 1: E, H multiples of 32 up to 1024 outside that set -- tg_gen_rollout, tg_gen_sample and
+ * tg_gen_nll only, with TG_GEN_SPLIT_F16 and V <= 65536 (the GEMM path); -1: not supported. */
 int tg_gen_supported(int V, int E, int H);
 
 /* ---------------------------------------------------------------------------

@@ -154,6 +154,8 @@ WIDE_CASES = [
     (20011, 64, 64, 5, 7, 3, 0.3),
     (32000, 32, 128, 8, 6, 2, 0.2),
     (50257, 64, 64, 6, 5, 2, 0.2),     # 50 groups per span: the draw kernel's second instantiation
+    (900, 160, 96, 7, 6, 2, 0.3),      # hidden / embedding sizes only the GEMM path takes
+    (600, 32, 768, 5, 5, 2, 0.05),
     (1500, 96, 32, 40, 9, 4, 0.5),
     (4099, 512, 512, 3, 5, 2, 0.05),
 ]
@@ -169,6 +171,10 @@ def test_rollout_wide_shapes_against_oracle(V, E, H, B, L, R, std, precision):
     gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
     og = oracle.Gen(gsd)
     sent, u = synth.tokens(21, (B, L), V), synth.uniform01(22, (R, L, L, B))
+    if precision == "fp32" and tg._lib.lib().tg_gen_supported(V, E, H) == 1:
+        with pytest.raises(RuntimeError, match="not supported"):  # hidden sizes outside the fp32 kernels' set
+            tg.ops.gen_rollout(gen, _t(sent), R, _t(u), precision=precision)
+        return
     ref = oracle.gen_rollout(og, sent, R, u)
     tg._lib.profile_enable(True)
     tg._lib.profile_read()
@@ -186,7 +192,7 @@ def test_rollout_wide_shapes_against_oracle(V, E, H, B, L, R, std, precision):
     assert (part[0] == -1).all() and (part[1:, :1] == -1).all() and (part[1:, 4:] == -1).all()
 
 
-@pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1)])
+@pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1), (900, 96, 160, 33, 5, 0.2)])
 def test_sample_wide_shapes_against_oracle(V, E, H, N, L, std):
     gsd = synth.gen_state(V, E, H, seed=12, std=std)
     gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
@@ -194,13 +200,16 @@ def test_sample_wide_shapes_against_oracle(V, E, H, N, L, std):
     u = synth.uniform01(23, (L, N))
     ref = oracle.gen_sample(og, N, L, 1, u)
     for precision in GEN_PRECISIONS:
+        if precision == "fp32" and tg._lib.lib().tg_gen_supported(V, E, H) == 1:
+            continue  # hidden sizes outside the fp32 kernels' set: GEMM path only
         out = tg.ops.gen_sample(gen, N, L, 1, _t(u), forced=_t(ref), precision=precision).cpu().numpy()
         assert (out == ref).mean() >= 0.999
         free = tg.ops.gen_sample(gen, N, L, 1, _t(u), precision=precision).cpu().numpy()
         assert (free == ref).all(-1).mean() >= 0.97
 
 
-@pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1), (4099, 512, 512, 19, 4, 0.05)])
+@pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1), (4099, 512, 512, 19, 4, 0.05),
+                                           (900, 96, 160, 33, 5, 0.2)])
 def test_nll_wide_shapes_against_oracle(V, E, H, N, L, std):
     """tg_gen_nll beyond E = H = 32: split_f16 takes the GEMM path (log-sum-exp from the tile records, the target's
     logit an fp32 dot product), fp32 the persistent kernel; both within the 1e-5 NLL bar of the oracle."""
@@ -211,6 +220,8 @@ def test_nll_wide_shapes_against_oracle(V, E, H, N, L, std):
     inp = np.concatenate([np.ones((N, 1), np.int64), tgt[:, :-1]], 1)
     o = oracle.gen_teacher_forced(og, inp, tgt)
     for precision in GEN_PRECISIONS:
+        if precision == "fp32" and tg._lib.lib().tg_gen_supported(V, E, H) == 1:
+            continue
         tg._lib.profile_enable(True)
         tg._lib.profile_read()
         lp, lse = tg.ops.gen_nll(gen, _t(inp), _t(tgt), precision=precision, want_lse=True)

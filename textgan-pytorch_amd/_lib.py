@@ -156,9 +156,11 @@ def gen_weights(gen, precision=None):
     if keep[1].shape != (4 * H, E) or keep[5].shape != (V, H):
         raise RuntimeError("textgan_hip: generator parameter shapes are inconsistent")
     w = GenW(*ptrs, V, E, H, PRECISIONS[precision or default_gen_precision])
-    if lib().tg_gen_supported(V, E, H) != 0:
+    sup = lib().tg_gen_supported(V, E, H)
+    if sup < 0 or (sup == 1 and (precision or default_gen_precision) != "split_f16"):
         raise RuntimeError("textgan_hip: generator shape V=%d E=%d H=%d is not supported by the compiled kernels "
-                           "(H in {32,64,128,256,512}, E a multiple of 32)" % (V, E, H))
+                           "(every entry point: H in {32,64,128,256,512}, E a multiple of 32 up to 512; rollout / sample "
+                           "/ NLL in split_f16: E, H multiples of 32 up to 1024)" % (V, E, H))
     return w, keep
 
 

@@ -976,17 +976,22 @@ size_t smem_bytes(const SamplerGeom& g, bool sample, int E, int H, bool lean = f
     return b + region;
 }
 
-int check_weights(const TgGenWeights* w) {
+// wide_ok: the entry point has a GEMM-path implementation (tg_genw.hip), which takes any E, H multiple of 32
+int check_weights(const TgGenWeights* w, bool wide_ok = false) {
     if (!w || !w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out) {
         tg_set_error("generator weights: null pointer");
         return TG_ERR_ARG;
     }
-    if (tg_gen_supported(w->V, w->E, w->H) != 0) {
-        tg_set_error("generator shape V=%d E=%d H=%d not supported by this build "
-                     "(H in {32,64,128,256,512}, E a multiple of 32 up to 512)", w->V, w->E, w->H);
-        return TG_ERR_ARG;
-    }
-    return TG_OK;
+    const int sup = tg_gen_supported(w->V, w->E, w->H);
+    if (sup == 0 || (sup == 1 && wide_ok && tg_genw_applies(w))) return TG_OK;
+    if (sup == 1)
+        tg_set_error("generator shape V=%d E=%d H=%d is served by the split-fp16 GEMM path only (tg_gen_rollout, "
+                     "tg_gen_sample, tg_gen_nll with TG_GEN_SPLIT_F16, V <= 65536); the fp32 kernels need "
+                     "H in {32,64,128,256,512} and E <= 512", w->V, w->E, w->H);
+    else
+        tg_set_error("generator shape V=%d E=%d H=%d not supported by this build (E, H multiples of 32 up to 1024)",
+                     w->V, w->E, w->H);
+    return TG_ERR_ARG;
 }
 
 template <bool SAMPLE, int HT, bool REG, bool SPLIT = false, int WPE = 2>
@@ -1043,8 +1048,9 @@ int launch(const GenArgs& a, int grid, hipStream_t stream) {
 }  // namespace
 
 extern "C" int tg_gen_supported(int V, int E, int H) {
-    const bool h_ok = H == 32 || H == 64 || H == 128 || H == 256 || H == 512;
-    return (V >= 1 && h_ok && E >= 32 && E <= 512 && (E % 32) == 0) ? 0 : -1;
+    if (V < 1 || E < 32 || H < 32 || E > 1024 || H > 1024 || (E % 32) || (H % 32)) return -1;
+    const bool h_pow2 = H == 32 || H == 64 || H == 128 || H == 256 || H == 512;
+    return (h_pow2 && E <= 512) ? 0 : 1;
 }
 extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
                                      float* logp_out, float* lse_out, float* logits_out, float* states_out,
@@ -1078,7 +1084,7 @@ extern "C" size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w, int N) {
 
 extern "C" int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
                           float* logp_out, float* lse_out, void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_weights(w);
+    int rc = check_weights(w, true);
     if (rc) return rc;
     if (!inp || !target || !logp_out || N < 0 || L < 1) {
         tg_set_error("tg_gen_nll: bad arguments (N=%d L=%d)", N, L);
@@ -1126,7 +1132,7 @@ extern "C" size_t tg_gen_sample_workspace_bytes(const TgGenWeights* w, int N) {
 extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int L, int R, int g_lo, int g_hi,
                               int i_lo, int i_hi, const float* uniforms, const int64_t* forced, int64_t* completions,
                               void* workspace, size_t workspace_bytes, void* stream) {
-    int rc = check_weights(w);
+    int rc = check_weights(w, true);
     if (rc) return rc;
     if (!sentences || !uniforms || !completions || B < 1 || L < 1 || R < 1 || g_lo < 1 || g_hi > L || g_lo > g_hi ||
         i_lo < 0 || i_hi > R || i_lo > i_hi) {
@@ -1182,7 +1188,7 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
 extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter, const float* uniforms,
                              const int64_t* forced, int64_t* out, void* workspace, size_t workspace_bytes,
                              void* stream) {
-    int rc = check_weights(w);
+    int rc = check_weights(w, true);
     if (rc) return rc;
     if (!uniforms || !out || N < 0 || L < 1 || start_letter < 0 || start_letter >= w->V) {
         tg_set_error("tg_gen_sample: bad arguments (N=%d L=%d start=%lld)", N, L, (long long)start_letter);

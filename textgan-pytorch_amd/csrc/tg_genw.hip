@@ -1038,7 +1038,7 @@ int check_shape(const TgGenWeights& w, const Geom& g) {
 
 bool tg_genw_applies(const TgGenWeights* w) {
     return w->precision == TG_GEN_SPLIT_F16 && !(w->E == 32 && w->H == 32) && w->H % 32 == 0 && w->E % 32 == 0 &&
-           make_geom(*w).NG <= kMaxNG;
+           w->H >= 32 && w->E >= 32 && w->H <= 1024 && w->E <= 1024 && w->V >= 1 && make_geom(*w).NG <= kMaxNG;
 }
 
 static size_t chunk_rows_rollout(int B, int L, int n_i, int* nIc_out) {
