@@ -339,7 +339,9 @@ def main():
         # flops one rank EXECUTES per get_reward call, per kernel (prefix-reuse conv: fresh windows only; the
         # reference-equivalent conv work, every window of every completion, is reported beside it)
         per_call = {"dis_conv": conv_fresh_bi * B * r_local, "dis_highway": hw_f * n_local,
-                    "gen_sample": gen_f * draws, "genw_proj": 2 * H * V * draws, "genw_cell": 8 * H * (E + H) * cell_steps}
+                    "gen_sample": gen_f * draws, "genw_proj": 2 * H * V * draws,
+                    # the cell GEMM executes the W_hh . h part; W_ih . x comes from a per-call table over the vocabulary
+                    "genw_cell": 8 * H * H * (cell_steps + B * (L - 1))}
         f16 = {"dis_conv": split, "dis_highway": split, "gen_sample": gsplit, "genw_proj": True, "genw_cell": True}
         peaks = {k: PEAK_F16_MFMA_TFLOPS if v else PEAK_FP32_MFMA_TFLOPS for k, v in f16.items()}
         # split-f16 kernels issue three fp16 MFMA products per algorithmic multiply-add

@@ -68,7 +68,7 @@ size_t al256(size_t x) { return (x + 255) / 256 * 256; }
 struct Carve {  // workspace layout
     unsigned* absmax; Scales* sc; float* bias2; float* gb;
     f32x4* a_proj; f32x4* a_cell; _Float16* emb_hi; _Float16* emb_lo;
-    f32x4* hfrag[2]; f32x4* cfrag; float2* rec; int* tok;
+    f32x4* hfrag[2]; f32x4* cfrag; float2* rec; int* tok; float* gx;
     size_t bytes;
 };
 
@@ -85,6 +85,7 @@ Carve carve(const Geom& g, size_t rowsP, void* base) {
     c.a_cell = reinterpret_cast<f32x4*>(take((size_t)(4 * g.H / 32) * g.KBc * 128 * 16));
     c.emb_hi = reinterpret_cast<_Float16*>(take((size_t)g.V * g.E * 2));
     c.emb_lo = reinterpret_cast<_Float16*>(take((size_t)g.V * g.E * 2));
+    c.gx = reinterpret_cast<float*>(take((size_t)g.V * 4 * g.H * sizeof(float)));
     const size_t RB = rowsP / 32;
     c.hfrag[0] = reinterpret_cast<f32x4*>(take(RB * g.KBh * 128 * 16));
     c.hfrag[1] = reinterpret_cast<f32x4*>(take(RB * g.KBh * 128 * 16));
@@ -252,7 +253,8 @@ __device__ __forceinline__ size_t rec_index(int row, int tile, int ntiles) {
 
 // ------------------------------------------------------------------ the GEMM
 struct GemmArgs {
-    const f32x4* A;   // fragments [MB][KB][2][64]
+    const f32x4* A;   // fragments [MB][KBA][2][64]; this GEMM runs over k blocks kbA0 .. kbA0 + KB - 1 of them
+    int KBA, kbA0;
     int KB, MT, RT;   // k blocks, M tiles, N (completion) tiles of the workgroup shape
     int NB;           // logical tiles: 8 * MT * ceil(RT / 8)
     const f32x4* Bh;  // hfrag (PROJ: the whole B operand; CELL: k blocks KBe..)
@@ -261,6 +263,8 @@ struct GemmArgs {
     const Scales* sc;
     const float* bias2; float2* rec; int ntiles;  // PROJ epilogue
     const float* gb; f32x4* cfrag; f32x4* hdst; int H;  // CELL epilogue
+    float* gx;        // gate table [V][H/8][2][4][4]: W_ih . emb[v] + b_ih + b_hh in the CELL epilogue's lane order
+    int table;        // 1: this launch fills gx (rows = vocabulary entries, x part only); 0: cell update reading it
 };
 
 // WM x WN waves, each TM x TN MFMA tiles of 32 x 32: workgroup tile (32 WM TM) x (32 WN TN).
@@ -311,16 +315,44 @@ __device__ __forceinline__ void epilogue_cell(const GemmArgs& a, const f32x16 (&
                                               int lane) {
     const float inv = a.sc->invCell;
     const int H = a.H;
+    if (a.table) {
+        // gx[v][T][hh][gate][unit] = W_ih . emb[v] + b_ih + b_hh: 64 B per lane, the order the update below reads
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi) {
+            const int T = mbw + mi;
+            const int u0 = 8 * T + 4 * hh;
+            f32x4 gbias[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gbias[q] = *reinterpret_cast<const f32x4*>(a.gb + q * H + u0);
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int v = (rbw + ni) * 32 + n;
+                if (v >= a.V) continue;
+                f32x4* d = reinterpret_cast<f32x4*>(a.gx + (((size_t)v * (H >> 3) + T) * 2 + hh) * 16);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaf(acc[mi][ni][4 * q + e], inv, gbias[q][e]);
+                    __builtin_nontemporal_store(o, d + q);
+                }
+            }
+        }
+        return;
+    }
+    int tokv[TN];
+#pragma unroll
+    for (int ni = 0; ni < TN; ++ni) tokv[ni] = tg_min(tg_max(a.tok[(rbw + ni) * 32 + n], 0), a.V - 1);
 #pragma unroll
     for (int mi = 0; mi < TM; ++mi) {
         const int T = mbw + mi;
-        const int u0 = 8 * T + 4 * hh;
-        f32x4 gbias[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) gbias[q] = *reinterpret_cast<const f32x4*>(a.gb + q * H + u0);
 #pragma unroll
         for (int ni = 0; ni < TN; ++ni) {
             const int rb = rbw + ni;
+            const f32x4* gp = reinterpret_cast<const f32x4*>(a.gx + (((size_t)tokv[ni] * (H >> 3) + T) * 2 + hh) * 16);
+            f32x4 gbias[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) gbias[q] = __builtin_nontemporal_load(gp + q);  // (a 262 MB table at C3: streamed, not cached)
             f32x4* cp = a.cfrag + ((size_t)rb * (H >> 3) + T) * 64 + lane;
             const f32x4 c_old = *cp;
             f32x4 c_new, h_new;
@@ -391,8 +423,10 @@ void k_genw_gemm(const GemmArgs a) {
     auto load_tok = [&](int rb, int (&t)[NLB]) {
         if constexpr (!PROJ) {
 #pragma unroll
-            for (int i = 0; i < NLB; ++i)
-                t[i] = tg_min(tg_max(a.tok[(rb + ((tid + i * NTHR) >> 8)) * 32 + (tid & 31)], 0), a.V - 1);
+            for (int i = 0; i < NLB; ++i) {
+                const int row = (rb + ((tid + i * NTHR) >> 8)) * 32 + (tid & 31);
+                t[i] = tg_min(tg_max(a.table ? row : a.tok[row], 0), a.V - 1);  // table launch: row v is token v
+            }
         }
     };
     load_tok(rb0, tokr);
@@ -401,7 +435,8 @@ void k_genw_gemm(const GemmArgs a) {
         f32x4* d = lds + buf * STAGE + tid;
 #pragma unroll
         for (int i = 0; i < NLA; ++i) {
-            const f32x4* g = a.A + ((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw;
+            const f32x4* g = PROJ ? a.A + ((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw
+                                  : a.A + ((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KBA + a.kbA0 + 2 * s) * 128 + pw;
             if constexpr (GLDS) glds16(g, d + i * NTHR);
             else pa[i] = *g;
         }
@@ -964,19 +999,20 @@ bool big_tiles(int m_blocks, int rows) {
 
 bool use_glds() { return diag_env("TG_GENW_GLDS") != '0'; }  // DIAG build: "0" = register staging in the 256 x 256 GEMMs
 
-void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
+// which = 0: vocabulary projection + sampler records; 1: cell update (W_hh . h on the matrix cores, the W_ih . x part
+// and the bias from the gate table); 2: fills the gate table for every vocabulary entry (once per call)
+void launch_gemm(int which, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
                  int hdst, hipStream_t st) {
     GemmArgs a = {};
     a.KBh = g.KBh;
-    a.KBe = g.KBe;
     a.sc = c.sc;
     a.H = g.H;
     a.E = g.E;
     a.V = g.V;
     a.Bh = c.hfrag[hsrc];
-    if (proj) {
+    if (which == 0) {
         a.A = c.a_proj;
-        a.KB = g.KBh;
+        a.KB = a.KBA = g.KBh;
         a.bias2 = c.bias2;
         a.rec = c.rec;
         a.ntiles = g.MBp * 2;
@@ -988,20 +1024,40 @@ void launch_gemm(bool proj, const TgGenWeights& w, const Geom& g, const Carve& c
         tg_prof_end(st);
     } else {
         a.A = c.a_cell;
-        a.KB = g.KBc;
+        a.KBA = g.KBc;
         a.emb_hi = c.emb_hi;
         a.emb_lo = c.emb_lo;
         a.tok = c.tok;
         a.gb = c.gb;
+        a.gx = c.gx;
         a.cfrag = c.cfrag;
         a.hdst = c.hfrag[hdst];
-        tg_prof_begin(TG_KERNEL_GENW_CELL, st);
+        if (which == 2) {  // x part: k blocks [0, KBe), every stage gathered from the embedding tables
+            a.table = 1;
+            a.kbA0 = 0;
+            a.KB = a.KBe = g.KBe;
+            rows = g.V;
+        } else {           // h part: k blocks [KBe, KBe + KBh)
+            a.kbA0 = g.KBe;
+            a.KB = g.KBh;
+            a.KBe = 0;
+        }
+        if (which == 1) tg_prof_begin(TG_KERNEL_GENW_CELL, st);
         if (big_tiles(4 * g.H / 32, rows) && use_glds()) launch_gemm_t<false, 2, 4, 4, 2, true>(a, 4 * g.H / 32, rows, st);
         else if (big_tiles(4 * g.H / 32, rows)) launch_gemm_t<false, 2, 4, 4, 2>(a, 4 * g.H / 32, rows, st);
         else if (use_glds()) launch_gemm_t<false, 2, 2, 2, 2, true>(a, 4 * g.H / 32, rows, st);
         else launch_gemm_t<false, 2, 2, 2, 2>(a, 4 * g.H / 32, rows, st);
-        tg_prof_end(st);
+        if (which == 1) tg_prof_end(st);
     }
+}
+
+// scales, operand fragments, fp16 embedding tables, then the gate table of every vocabulary entry (one GEMM per call)
+int prep_all(const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, hipStream_t st) {
+    int rc = prep_weights(w, g, c, st);
+    if (rc) return rc;
+    launch_gemm(2, w, g, c, rowsP, g.V, 0, 0, st);
+    GW_CHECK_LAUNCH("k_genw gate table");
+    return TG_OK;
 }
 
 void launch_draw(const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, const RowMap& map, int rows, int t,
@@ -1075,7 +1131,7 @@ int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int 
         return TG_ERR_WORKSPACE;
     }
     if ((rc = ensure_lds())) return rc;
-    if ((rc = prep_weights(*w, g, c, st))) return rc;
+    if ((rc = prep_all(*w, g, c, rowsP, st))) return rc;
     const int g_hs = g_hi < L - 1 ? g_hi : L - 1;  // given_num = L only copies
     if (g_hs >= g_lo) {
         // states[t] = (h, c) of every sentence after its first t tokens, t = 1..g_hs, with the same cell GEMM
@@ -1085,7 +1141,7 @@ int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int 
         int p = 0;
         for (int t = 1; t <= g_hs; ++t) {
             hipLaunchKernelGGL(k_genw_tok_col, dim3((B + 255) / 256), dim3(256), 0, st, sentences, B, L, t - 1, g.V, c.tok);
-            launch_gemm(false, *w, g, c, rowsP, B, p, 1 - p, st);
+            launch_gemm(1, *w, g, c, rowsP, B, p, 1 - p, st);
             p = 1 - p;
             if (t >= g_lo)
                 hipLaunchKernelGGL(k_genw_export, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, c.hfrag[p], c.cfrag,
@@ -1120,13 +1176,13 @@ int tg_genw_rollout(const TgGenWeights* w, const int64_t* sentences, int B, int 
             const int a_t = ((t < g_hs ? t : g_hs) - g_lo + 1) * nIB;
             // rows that drew position t-1 take a cell step on that token; rows with given_num == t enter with the
             // state after their t prefix tokens (utils/rollout.py:35-38)
-            if (a_prev > 0) launch_gemm(false, *w, g, c, rowsP, a_prev, p, 1 - p, st);
+            if (a_prev > 0) launch_gemm(1, *w, g, c, rowsP, a_prev, p, 1 - p, st);
             if (t <= g_hs) {
                 const size_t n = (size_t)(a_t - a_prev) * (g.H / 4);
                 hipLaunchKernelGGL(k_genw_enter, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st,
                                    states + (size_t)t * B * 2 * g.H, B, g.H, g.KBh, a_prev, a_t, c.hfrag[1 - p], c.cfrag);
             }
-            launch_gemm(true, *w, g, c, rowsP, a_t, 1 - p, 0, st);
+            launch_gemm(0, *w, g, c, rowsP, a_t, 1 - p, 0, st);
             launch_draw(*w, g, c, rowsP, map, a_t, t, 1 - p, uniforms, forced, completions, st);
             p = 1 - p;
         }
@@ -1153,7 +1209,7 @@ int tg_genw_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target
         return TG_ERR_WORKSPACE;
     }
     if ((rc = ensure_lds())) return rc;
-    if ((rc = prep_weights(*w, g, c, st))) return rc;
+    if ((rc = prep_all(*w, g, c, rowsP, st))) return rc;
     for (size_t n0 = 0; n0 < (size_t)N; n0 += rows_c) {
         const int rows = (int)(((size_t)N - n0) < rows_c ? ((size_t)N - n0) : rows_c);
         hipLaunchKernelGGL(k_genw_fill_tok, dim3((unsigned)((rowsP + 255) / 256)), dim3(256), 0, st, c.tok, rowsP, 0);
@@ -1164,8 +1220,8 @@ int tg_genw_nll(const TgGenWeights* w, const int64_t* inp, const int64_t* target
         for (int t = 0; t < L; ++t) {
             hipLaunchKernelGGL(k_genw_tok_col, dim3((rows + 255) / 256), dim3(256), 0, st, inp + n0 * L, rows, L, t, g.V,
                                c.tok);
-            launch_gemm(false, *w, g, c, rowsP, rows, p, 1 - p, st);
-            launch_gemm(true, *w, g, c, rowsP, rows, 1 - p, 0, st);
+            launch_gemm(1, *w, g, c, rowsP, rows, p, 1 - p, st);
+            launch_gemm(0, *w, g, c, rowsP, rows, 1 - p, 0, st);
             LseArgs a = {};
             a.g = g;
             a.rec = c.rec;
@@ -1202,7 +1258,7 @@ int tg_genw_sample(const TgGenWeights* w, int N, int L, int64_t start_letter, co
         return TG_ERR_WORKSPACE;
     }
     if ((rc = ensure_lds())) return rc;
-    if ((rc = prep_weights(*w, g, c, st))) return rc;
+    if ((rc = prep_all(*w, g, c, rowsP, st))) return rc;
     for (size_t n0 = 0; n0 < (size_t)N; n0 += rows_c) {
         const int rows = (int)(((size_t)N - n0) < rows_c ? ((size_t)N - n0) : rows_c);
         RowMap map = {};
@@ -1219,8 +1275,8 @@ int tg_genw_sample(const TgGenWeights* w, int N, int L, int64_t start_letter, co
         }
         int p = 0;
         for (int t = 0; t < L; ++t) {
-            launch_gemm(false, *w, g, c, rowsP, rows, p, 1 - p, st);
-            launch_gemm(true, *w, g, c, rowsP, rows, 1 - p, 0, st);
+            launch_gemm(1, *w, g, c, rowsP, rows, p, 1 - p, st);
+            launch_gemm(0, *w, g, c, rowsP, rows, 1 - p, 0, st);
             launch_draw(*w, g, c, rowsP, map, rows, t, 1 - p, uniforms, forced, out, st);
             p = 1 - p;
         }
