@@ -116,8 +116,9 @@ extern "C" int tg_allgather_rows(float* raw, size_t rows_per_rank, size_t B, voi
     }
     typedef int (*rank_fn)(void*, int*);
     typedef int (*gather_fn)(const void*, void*, size_t, int, void*, void*);
-    static rank_fn f_rank = reinterpret_cast<rank_fn>(dlsym(RTLD_DEFAULT, "ncclCommUserRank"));
-    static gather_fn f_gather = reinterpret_cast<gather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
+    // looked up per call: the library that owns `comm` may have been loaded after an earlier, failed call
+    const rank_fn f_rank = reinterpret_cast<rank_fn>(dlsym(RTLD_DEFAULT, "ncclCommUserRank"));
+    const gather_fn f_gather = reinterpret_cast<gather_fn>(dlsym(RTLD_DEFAULT, "ncclAllGather"));
     if (!f_rank || !f_gather) {
         tg_set_error("tg_allgather_rows: no RCCL in this process (ncclAllGather not found)");
         return TG_ERR_LAUNCH;

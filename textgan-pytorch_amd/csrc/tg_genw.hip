@@ -1001,7 +1001,7 @@ bool use_glds() { return diag_env("TG_GENW_GLDS") != '0'; }  // DIAG build: "0" 
 
 // which = 0: vocabulary projection + sampler records; 1: cell update (W_hh . h on the matrix cores, the W_ih . x part
 // and the bias from the gate table); 2: fills the gate table for every vocabulary entry (once per call)
-void launch_gemm(int which, const TgGenWeights& w, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
+void launch_gemm(int which, const TgGenWeights& /*w*/, const Geom& g, const Carve& c, size_t rowsP, int rows, int hsrc,
                  int hdst, hipStream_t st) {
     GemmArgs a = {};
     a.KBh = g.KBh;
