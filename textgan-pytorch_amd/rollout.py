@@ -24,6 +24,10 @@ class ROLLOUT:
     #: dropout masks of the scorer when no dropout_uniforms are passed: "kernel" = counter-based, generated inside the
     #: highway epilogue from a per-call seed (no [N, F] tensor); "torch" = torch.rand uniforms (ROLLOUT.generator)
     dropout_rng = "kernel"
+    #: with a process group: broadcast the generator's and the scorer's weights from rank 0 of the group at the top of
+    #: every get_reward call (once per adversarial step); switch off when the trainer keeps the
+    #: replicas equal by other means (DDP, an explicit tg.dist.sync_weights)
+    sync_weights = True
 
     def __init__(self, gen, gpu=True):
         self.gen = gen
@@ -34,7 +38,8 @@ class ROLLOUT:
         self.goal_out_size = gen.goal_out_size if getattr(gen, "name", None) == "leakgan" else 0
         self.gpu = gpu
         self.generator = None           # optional torch.Generator for the uniforms
-        self.group = None               # optional torch.distributed process group
+        self.group = None               # sharding is opt-in: tg.dist.WORLD (default group) or a ProcessGroup
+        self._rank_gens = {}            # (device, rank) -> torch.Generator of a sharded call's private uniforms
         self.timers = None              # optional dict name -> list[(start_event, end_event)]
         _lib.lib()                      # fail loudly here if the HIP extension is missing
 
@@ -55,8 +60,20 @@ class ROLLOUT:
         if sentences.dim() != 2 or sentences.shape[1] != self.max_seq_len:
             raise RuntimeError("textgan_hip ROLLOUT: sentences must be [batch, %d]" % self.max_seq_len)
 
-    def _rand(self, shape, device):
-        return torch.rand(shape, dtype=torch.float32, device=device, generator=self.generator)
+    def _rand(self, shape, device, plan=None):
+        """U[0,1) draws.  Single rank: ROLLOUT.generator (None = torch's default).  Sharded: every rank holds the same
+        torch seed, so each draws from a private generator seeded from (base seed, rank) -- otherwise rank k's
+        completions would be bit-copies of rank 0's and the effective rollout_num R / world."""
+        gen = self.generator
+        if plan is not None and plan.world > 1:
+            key = (str(device), plan.rank)
+            gen = self._rank_gens.get(key)
+            if gen is None:
+                base = self.generator.initial_seed() if self.generator is not None else torch.initial_seed()
+                gen = torch.Generator(device=device)
+                gen.manual_seed(tdist.rank_seed(base, plan.rank))
+                self._rank_gens[key] = gen
+        return torch.rand(shape, dtype=torch.float32, device=device, generator=gen)
 
     # ------------------------------------------------------------------ reference API
     def rollout_mc_search(self, sentences, given_num, uniforms=None):
@@ -76,7 +93,9 @@ class ROLLOUT:
         """utils/rollout.py:128-154.
 
         uniforms          optional [R,L,L,B] pre-drawn U[0,1) (index [i, given_num-1, t, b]); drawn with
-                          torch.rand when omitted.  With a process group it is the GLOBAL tensor.
+                          torch.rand when omitted.  With a process group (ROLLOUT.group) an explicit tensor is
+                          the GLOBAL one, identical on every rank; omitted, every rank draws its own rows from a
+                          private generator seeded from (seed, rank).
         dropout_uniforms  optional [R*L, B, F] for the discriminator's live dropout (the reference never
                           calls dis.eval(), so dropout is active whenever dis.training is True)."""
         self._check(sentences)
@@ -86,8 +105,11 @@ class ROLLOUT:
         plan = tdist.ShardPlan.from_group(R, self.group)
         Rl = plan.i_hi - plan.i_lo
         with torch.no_grad():
+            if plan.world > 1 and self.sync_weights:
+                with self._timed("sync_weights"):
+                    tdist.sync_weights(self.gen, dis, self.group)
             if uniforms is None:
-                u = self._rand((Rl, L, L, B), dev)
+                u = self._rand((Rl, L, L, B), dev, plan)
             else:
                 u = uniforms.reshape(R, L, L, B)[plan.i_lo:plan.i_hi].contiguous()
             raw_local = torch.empty(Rl * L, B, dtype=torch.float32, device=dev)
@@ -110,7 +132,7 @@ class ROLLOUT:
                         if p > 0 and du_all is not None:
                             du = du_all[lo * L * B:hi * L * B].contiguous()
                         elif p > 0 and self.dropout_rng == "torch":
-                            du = self._rand(((hi - lo) * L * B, F), dev)
+                            du = self._rand(((hi - lo) * L * B, F), dev, plan)
                         elif p > 0:
                             seed = _lib.next_dropout_seed(plan.rank)
                         ops.dis_score_rollout(dis, sentences, comp[lo:hi], col=current_k + 1, dropout_p=p,
