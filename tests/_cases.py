@@ -53,11 +53,22 @@ def sampled_mask(R, L, B):
     return np.broadcast_to((t >= g)[None, :, None, :], (R, L, B, L))
 
 
-def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, tie_tol=2e-5, max_check=200):
+#: largest |cdf - u| seen at a token disagreement, per test id (written to gpurun_out/tie_stats.json at session end)
+TIE_STATS = {}
+
+
+def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, tie_tol=1e-6, max_check=1000, what=None):
     """Step-wise (replay-mode) token parity, north_star's criterion: >= 99.9 % of
     sampled positions identical, and every disagreement a CDF tie within fp32
-    epsilon.  got_replay / ref: [R,L,B,L] completions, got_replay produced with
-    forced=ref; uniforms [R,L,L,B]."""
+    rounding.  got_replay / ref: [R,L,B,L] completions, got_replay produced with
+    forced=ref; uniforms [R,L,L,B].
+
+    tie_tol: the disagreeing tokens must be neighbours in CDF order with every boundary between them within
+    tie_tol of u.  1e-6 is what fp32 leaves at a boundary: the cumulative probability there is a sum of V terms
+    exp(logit - max) whose logits carry ~1e-6 relative error (H-term fp32 dot products of magnitude up to ~15 with
+    N(0,1) weights), far above the 1.2e-7 of a single fp32 rounding, far below the 2e-5 accepted in round 1.  Every
+    disagreement is inspected (up to max_check = 1000 per call; more than that fails min_agree on any case here)."""
+    import os
     from oracle import oracle
     R, L, B, _ = ref.shape
     m = sampled_mask(R, L, B)
@@ -65,7 +76,9 @@ def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, t
     agree = 1.0 - diff.sum() / max(1, m.sum())
     assert agree >= min_agree, "step-wise token agreement %.6f" % agree
     assert np.array_equal(got_replay[~m], ref[~m]), "prefix tokens must be copied verbatim"
-    idx = np.argwhere(diff)[:max_check]
+    idx = np.argwhere(diff)
+    assert len(idx) <= max_check, "%d disagreements: more than the %d this check inspects" % (len(idx), max_check)
+    worst = 0.0
     for (i, gi, b, t) in idx:
         row = ref[i, gi, b].astype(np.int64)
         r = oracle.gen_teacher_forced(gen_oracle, row[None, :], want_logits=True)
@@ -76,7 +89,14 @@ def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, t
         u = float(uniforms[i, gi, t, b])
         lo, hi = min(a, c), max(a, c)
         # every boundary between the two tokens must sit within tie_tol of u
-        assert np.all(np.abs(cdf[lo:hi] - u) <= tie_tol), (i, gi + 1, b, t, a, c, u, cdf[lo:hi])
+        gap = float(np.abs(cdf[lo:hi] - u).max())
+        assert gap <= tie_tol, (i, gi + 1, b, t, a, c, u, cdf[lo:hi])
+        worst = max(worst, gap)
+    key = what or os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    st = TIE_STATS.setdefault(key, {"draws": 0, "disagreements": 0, "max_tie_gap": 0.0})
+    st["draws"] += int(m.sum())
+    st["disagreements"] += int(len(idx))
+    st["max_tie_gap"] = max(st["max_tie_gap"], worst)
     return agree
 
 

@@ -183,13 +183,39 @@ def test_rollout_wide_shapes_against_oracle(V, E, H, B, L, R, std, precision):
     tg._lib.profile_enable(False)
     wide = precision == "split_f16"  # which kernels served the call
     assert (prof["genw_proj"][1] > 0) == wide and (prof["genw_draw"][1] > 0) == wide and (prof["gen_sample"][1] > 0) != wide
-    _cases.check_token_parity(replay.cpu().numpy(), ref, u, og, max_check=20)
+    _cases.check_token_parity(replay.cpu().numpy(), ref, u, og)
     free = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), precision=precision)
     assert (free.cpu().numpy() == ref).all(-1).mean() >= 0.97
     part = torch.full_like(free, -1)
     tg.ops.gen_rollout(gen, _t(sent), R, _t(u), g_lo=2, g_hi=4, i_lo=1, i_hi=R, out=part, precision=precision)
     assert torch.equal(part[1:, 1:4], free[1:, 1:4])
     assert (part[0] == -1).all() and (part[1:, :1] == -1).all() and (part[1:, 4:] == -1).all()
+
+
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+def test_rollout_scaled_config_shape_against_oracle(precision):
+    """BASELINE configs[2]'s exact generator shape (V 32 000, L 51, E = H = 512) against the oracle, at a batch the CPU
+    does in seconds (B 32, rollout_num 1: 1 632 completions, 40 800 draws, 1.3 TFLOP of projection on the host):
+    step-wise token parity with every disagreement a CDF tie, free-running rows, and the rewards of the rows that
+    agree (SeqGAN_D scorer, eval mode) within 1e-4."""
+    V, L, E, H, B, R = 32000, 51, 512, 512, 32, 1
+    gsd = synth.gen_state(V, E, H, seed=0, std=0.05)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=0)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), dsd, DEV).eval()
+    og, od = oracle.Gen(gsd), oracle.Dis(dsd)
+    sent, u = synth.tokens(1, (B, L), V), synth.uniform01(2, (R, L, L, B))
+    o = oracle.get_reward(og, od, sent, R, u)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"]), precision=precision)
+    _cases.check_token_parity(replay.cpu().numpy(), o["completions"], u, og)
+    ro = tg.ROLLOUT(gen)
+    ro.gen_precision = precision
+    rew, raw, comp = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), return_parts=True)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
+    assert same.mean() >= 0.98
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, L, R).all(-1)
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
 
 
 @pytest.mark.parametrize("V,E,H,N,L,std", [(20011, 64, 64, 70, 6, 0.3), (700, 32, 256, 130, 5, 0.1), (900, 96, 160, 33, 5, 0.2)])
@@ -246,7 +272,7 @@ def test_wide_generator_across_weight_scales(std, emb_scale, bias_scale):
     sent, u = synth.tokens(1, (B, L), V), synth.uniform01(2, (R, L, L, B))
     ref = oracle.gen_rollout(og, sent, R, u)
     replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision="split_f16").cpu().numpy()
-    _cases.check_token_parity(replay, ref, u, og, max_check=20)
+    _cases.check_token_parity(replay, ref, u, og)
 
 
 # ------------------------------------------------------------------ discriminator
@@ -303,8 +329,11 @@ def test_get_reward(name):
     same = (comp == c["completions"]).all(-1).reshape(R * L, B)
     assert same.mean() >= 0.98
     np.testing.assert_allclose(raw[same], c["raw"][same], atol=1e-4, rtol=0)
-    if same.all():
-        np.testing.assert_allclose(rew, c["reward"], atol=1e-4, rtol=0)
+    # out[b,t] = mean_r raw.flatten()[(b*L+t)*R + r] (utils/rollout.py:153): compare every output whose R contributing
+    # raw entries come from completions that agree -- one cascaded CDF tie no longer hides the whole [B,L] matrix
+    ok = same.reshape(B, L, R).all(-1)
+    assert ok.mean() >= 0.9
+    np.testing.assert_allclose(rew[ok], c["reward"][ok], atol=1e-4, rtol=0)
     # the scorer on the reference's own completions: every raw row within 1e-4, and the reduce
     d = tg.ops.dis_score(dis, _t(c["completions"].astype(np.int64).reshape(R * L * B, L)), col=int(c["current_k"]) + 1,
                          dropout_p=float(c["dropout_p"]),
@@ -363,13 +392,16 @@ def test_get_reward_c1_full_vs_oracle(precision):
     og, od = oracle.Gen(gsd), oracle.Dis(dsd)
     o = oracle.get_reward(og, od, sent, R, u)
     replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"]), precision=precision).cpu().numpy()
-    _cases.check_token_parity(replay, o["completions"], u, og, max_check=50)
+    _cases.check_token_parity(replay, o["completions"], u, og)
     ro = tg.ROLLOUT(gen)
     ro.gen_precision = precision
     rew, raw, comp = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), return_parts=True)
     same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
     assert same.mean() >= 0.98
     np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, L, R).all(-1)
+    assert ok.mean() >= 0.9
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
     # size-independent properties: rewards are probabilities, the g = L rows do not depend on i
     rw = raw.cpu().numpy().reshape(R, L, B)
     assert np.all((rw >= 0) & (rw <= 1))
@@ -389,7 +421,7 @@ def test_generator_split_precision_across_weight_scales(std, bias_scale):
     og = oracle.Gen(gsd)
     ref = oracle.gen_rollout(og, sent, R, u)
     replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision="split_f16").cpu().numpy()
-    _cases.check_token_parity(replay, ref, u, og, max_check=50)
+    _cases.check_token_parity(replay, ref, u, og)
 
 
 @pytest.mark.parametrize("conv_scale,emb_scale", [(1e-3, 1.0), (1e3, 1.0), (1.0, 1e-3), (30.0, 30.0)])
@@ -507,7 +539,7 @@ def test_wide_rollout_across_chunks_against_oracle():
     sent, u = synth.tokens(25, (B, L), V), synth.uniform01(26, (R, L, L, B))
     ref = oracle.gen_rollout(og, sent, R, u)
     replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision="split_f16")
-    _cases.check_token_parity(replay.cpu().numpy(), ref, u, og, max_check=20)
+    _cases.check_token_parity(replay.cpu().numpy(), ref, u, og)
     part = torch.full_like(replay, -1)
     tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), i_lo=25, i_hi=R, out=part, precision="split_f16")
     assert torch.equal(part[25:], replay[25:]) and bool((part[:25] == -1).all())
