@@ -191,8 +191,7 @@ int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
  *   dropout_uniforms [N,F] fp32 or NULL: explicit U[0,1) draws (keep iff u < 1-p);
  *                               NULL with dropout_p > 0 = counter-based masks from
  *                               TgDisWeights.dropout_seed
- *   dropout_uniforms [N,F]      or NULL; keep = u < 1-p, scale 1/(1-p)
- *                               (nn.Dropout, discriminator.py:36,47)
+ *                               kept values are scaled 1/(1-p) (nn.Dropout, discriminator.py:36,47)
  *   reward_out       [N]        or NULL
  *   logits_out       [N,n_out]  or NULL (feature2out outputs, parity tests)
  *   feature_out      [N,F]      or NULL (get_feature output, parity tests)

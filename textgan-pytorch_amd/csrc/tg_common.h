@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/textgan_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -113,7 +115,28 @@ inline long long* tg_diag_pointer(const char* env_name) {
 __device__ __forceinline__ int tg_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int tg_max(int a, int b) { return a > b ? a : b; }
 
-// host-side error plumbing and per-kernel event timing (tg_api.hip)
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the device that is current when it is called: one
+// record per kernel instantiation (a function-local static TgLdsAttr) remembers, per device, the largest size set,
+// so a second GPU used from the same thread gets its attribute too.  Setting it twice from two threads is harmless.
 void tg_set_error(const char* fmt, ...);
+struct TgLdsAttr { std::atomic<size_t> set[64]; };
+inline int tg_lds_attr(TgLdsAttr& st, const void* fn, size_t bytes, const char* what) {
+    if (bytes <= 48 * 1024) return TG_OK;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        tg_set_error("%s: hipGetDevice failed or device index out of range", what);
+        return TG_ERR_LAUNCH;
+    }
+    if (bytes <= st.set[dev].load(std::memory_order_relaxed)) return TG_OK;
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+        tg_set_error("hipFuncSetAttribute(%s, %zu bytes of LDS): %s", what, bytes, hipGetErrorString(e));
+        return TG_ERR_LAUNCH;
+    }
+    st.set[dev].store(bytes, std::memory_order_relaxed);
+    return TG_OK;
+}
+
+// host-side error plumbing and per-kernel event timing (tg_api.hip)
 void tg_prof_begin(int kernel_id, hipStream_t s);
 void tg_prof_end(hipStream_t s);

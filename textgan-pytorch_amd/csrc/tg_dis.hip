@@ -1208,16 +1208,8 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
 
 template <int MODE, bool SPLIT>
 int launch_conv_t(const ConvArgs& ca, size_t sm, hipStream_t stream) {
-    static thread_local size_t conv_set = 0;
-    if (sm > 48 * 1024 && sm > conv_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_conv<MODE, SPLIT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) {
-            tg_set_error("hipFuncSetAttribute(k_dis_conv): %s", hipGetErrorString(e));
-            return TG_ERR_LAUNCH;
-        }
-        conv_set = sm;
-    }
+    static TgLdsAttr attr;
+    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_dis_conv<MODE, SPLIT>), sm, "k_dis_conv")) return rc;
     tg_prof_begin(MODE == kConvStoreAll ? TG_KERNEL_DIS_PREFIX : TG_KERNEL_DIS_CONV, stream);
     // a grid of fewer workgroups than CUs (the sentence pass: B sequences) is widened over the (width, tile) items
     const int gx = (ca.N + ca.S - 1) / ca.S;
@@ -1316,16 +1308,8 @@ template <int WF, int WS, int NJ>
 int launch_highway_split(HsArgs& hs, hipStream_t stream) {
     constexpr int TF = 64 * WF, TS = 32 * NJ * WS;
     constexpr size_t sm = sizeof(_Float16) * 2 * (TF + TS) * kHsStride;
-    static thread_local bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_dis_highway_split<WF, WS, NJ>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) {
-            tg_set_error("hipFuncSetAttribute(k_dis_highway_split): %s", hipGetErrorString(e));
-            return TG_ERR_LAUNCH;
-        }
-        attr_set = true;
-    }
+    static TgLdsAttr attr;
+    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_dis_highway_split<WF, WS, NJ>), sm, "k_dis_highway_split")) return rc;
     hs.h.nchunk = (hs.h.w.F + TF - 1) / TF;
     hs.h.nseqtile = (hs.h.N + TS - 1) / TS;
     tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);

@@ -1002,16 +1002,8 @@ int launch_t(const GenArgs& a, int grid, hipStream_t stream) {
                      a.w.H);
         return TG_ERR_ARG;
     }
-    static thread_local size_t set_max = 0;
-    if (sm > 48 * 1024 && sm > set_max) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG, SPLIT, WPE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)sm);
-        if (e != hipSuccess) {
-            tg_set_error("hipFuncSetAttribute: %s", hipGetErrorString(e));
-            return TG_ERR_LAUNCH;
-        }
-        set_max = sm;
-    }
+    static TgLdsAttr attr;
+    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_gen<SAMPLE, HT, REG, SPLIT, WPE>), sm, "k_gen")) return rc;
     tg_prof_begin(SAMPLE ? TG_KERNEL_GEN_SAMPLE : TG_KERNEL_GEN_TEACHER, stream);
     hipLaunchKernelGGL((k_gen<SAMPLE, HT, REG, SPLIT, WPE>), dim3(grid), dim3(kThreads), sm, stream, a);
     tg_prof_end(stream);

@@ -929,8 +929,15 @@ int gemm_lds_attr() {
 }
 
 int ensure_lds() {
-    static thread_local bool done = false;
-    if (done) return TG_OK;
+    // per device (the attribute applies to the device that is current when it is set)
+    static std::atomic<bool> done_on[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+        tg_set_error("tg_genw: hipGetDevice failed or device index out of range");
+        return TG_ERR_LAUNCH;
+    }
+    std::atomic<bool>& done = done_on[dev];
+    if (done.load(std::memory_order_relaxed)) return TG_OK;
     int rc = gemm_lds_attr<true, 2, 2, 2, 2>();
     if (!rc) rc = gemm_lds_attr<false, 2, 2, 2, 2>();
     if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2>();
@@ -940,7 +947,7 @@ int ensure_lds() {
     if (!rc) rc = gemm_lds_attr<true, 2, 4, 4, 2, true>();
     if (!rc) rc = gemm_lds_attr<false, 2, 4, 4, 2, true>();
     if (rc) return rc;
-    done = true;
+    done.store(true, std::memory_order_relaxed);
     return TG_OK;
 }
 

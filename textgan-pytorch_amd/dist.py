@@ -26,6 +26,22 @@ def _resolve(group):
     return None if (isinstance(group, str) and group == WORLD) else group
 
 
+def _host_staged(g, t):
+    """gloo moves CUDA tensors through its own pinned buffers and streams, which proved unreliable with several ranks
+    on one device (a hung all_gather on the one-GPU test box): with a gloo group the collectives here run on host
+    copies instead.  RCCL ("nccl") groups take the device tensors directly."""
+    return t.is_cuda and dist.get_backend(g) == "gloo"
+
+
+def _all_gather_into(full, part, g):
+    if _host_staged(g, part):
+        host = torch.empty(full.shape, dtype=full.dtype)
+        dist.all_gather_into_tensor(host, part.cpu().contiguous(), group=g)
+        full.copy_(host)
+    else:
+        dist.all_gather_into_tensor(full, part.contiguous(), group=g)
+
+
 class ShardPlan:
     """Balanced contiguous split of range(R) over `world` ranks."""
 
@@ -65,13 +81,13 @@ def gather_rows(raw_local, plan, L, group=None):
     B = raw_local.shape[1]
     if plan.even:
         full = torch.empty(plan.R * L, B, dtype=raw_local.dtype, device=raw_local.device)
-        dist.all_gather_into_tensor(full, raw_local.contiguous(), group=g)
+        _all_gather_into(full, raw_local, g)
         return full
     # uneven split: pad every rank to max_count rollouts, gather, drop the padding
     pad = torch.zeros(plan.max_count * L, B, dtype=raw_local.dtype, device=raw_local.device)
     pad[:raw_local.shape[0]] = raw_local
     full = torch.empty(plan.world * plan.max_count * L, B, dtype=raw_local.dtype, device=raw_local.device)
-    dist.all_gather_into_tensor(full, pad, group=g)
+    _all_gather_into(full, pad, g)
     full = full.view(plan.world, plan.max_count * L, B)
     return torch.cat([full[k, :plan.counts[k] * L] for k in range(plan.world)], 0)
 
@@ -110,7 +126,12 @@ def sync_weights(gen, dis=None, group=WORLD, src=0):
             by_kind.setdefault((t.dtype, t.device), []).append(t)
         for (dtype, device), ts in by_kind.items():
             flat = torch.cat([t.detach().reshape(-1) for t in ts])
-            dist.broadcast(flat, src=root, group=g)
+            if _host_staged(g, flat):
+                host = flat.cpu()
+                dist.broadcast(host, src=root, group=g)
+                flat.copy_(host)
+            else:
+                dist.broadcast(flat, src=root, group=g)
             nbytes += flat.numel() * flat.element_size()
             off = 0
             for t in ts:

@@ -4,6 +4,7 @@ All tensors are CUDA (ROCm) tensors; work is enqueued on torch's current
 stream; outputs are allocated by torch and written by the HIP kernels.
 """
 import ctypes as C
+import functools
 
 import torch
 
@@ -12,12 +13,40 @@ from . import _lib
 I64, F32 = torch.int64, torch.float32
 
 
+def _on_device(fn):
+    """The C ABI launches on the CURRENT HIP device and stream: make the device of the call's tensors / modules
+    current for its duration (a rank that holds its tensors on cuda:k without torch.cuda.set_device(k) would
+    otherwise launch on device 0's stream against device-k pointers), and refuse a call that mixes devices."""
+    @functools.wraps(fn)
+    def wrapped(*args, **kw):
+        dev = None
+        for a in list(args) + list(kw.values()):
+            d = None
+            if isinstance(a, torch.Tensor):
+                d = a.device
+            elif isinstance(a, torch.nn.Module):
+                d = next((p.device for p in a.parameters()), None)
+            if d is None or d.type != "cuda":   # CPU tensors are diagnosed where their pointer is taken
+                continue
+            if dev is None:
+                dev = d
+            elif d != dev:
+                raise RuntimeError("textgan_hip: the tensors and modules of one call must live on one device "
+                                   "(got %s and %s)" % (dev, d))
+        if dev is None:
+            return fn(*args, **kw)
+        with torch.cuda.device(dev):
+            return fn(*args, **kw)
+    return wrapped
+
+
 def _tokens(t, name):
     if t.dtype != I64:
         t = t.long()
     return t.contiguous() if not t.is_contiguous() else t, name
 
 
+@_on_device
 def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, want_logits=False, want_states=False):
     """tg_gen_teacher_forced: LSTMGenerator.forward over [N,L] with zero initial state
     (models/generator.py:40-60).  Returns dict(logp [N,L], lse [N,L], logits [N,L,V], states [L+1,N,2,H])."""
@@ -36,6 +65,7 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 
+@_on_device
 def gen_nll(gen, inp, target, precision=None, want_lse=False):
     """tg_gen_nll: log-probabilities of the targets under teacher forcing (metrics/nll.py:59-61), in the
     library's default generator arithmetic or ``precision``.  Returns logp [N,L] (and lse if asked)."""
@@ -54,6 +84,7 @@ def gen_nll(gen, inp, target, precision=None, want_lse=False):
     return (logp, lse) if want_lse else logp
 
 
+@_on_device
 def gen_pg_forward(gen, inp, target):
     """tg_gen_pg_forward: logp / lse / states of a teacher-forced pass, row-parallel projection (few sequences).
     Same dict as gen_teacher_forced(want_lse=True, want_states=True)."""
@@ -71,6 +102,7 @@ def gen_pg_forward(gen, inp, target):
     return {"logp": logp, "lse": lse, "logits": None, "states": states}
 
 
+@_on_device
 def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1):
     """tg_gen_pg_backward: gradients of sum(coeff-weighted log-probabilities of the targets) with respect to the
     seven generator parameters (what autograd produces behind SeqGAN_G.batchPGLoss, models/SeqGAN_G.py:21-39).
@@ -93,6 +125,7 @@ def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1):
     return tuple(grads)
 
 
+@_on_device
 def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_lo=0, i_hi=None, out=None,
                 precision=None):
     """tg_gen_rollout: every rollout_mc_search(sentences, g) of get_reward's loops
@@ -116,6 +149,7 @@ def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_l
     return comp
 
 
+@_on_device
 def gen_sample(gen, N, L, start_letter, uniforms, forced=None, precision=None):
     """tg_gen_sample: the step loop of LSTMGenerator.sample (models/generator.py:71-81) for N rows.
     uniforms [L,N]; returns [N,L] int64 on the device."""
@@ -144,6 +178,7 @@ def _dropout_args(w, N, dropout_p, dropout_uniforms, dropout_seed, count):
     return None
 
 
+@_on_device
 def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_reward=True, want_logits=False,
               want_feature=False, reward_out=None, weights=None, precision=None, dropout_seed=None):
     """tg_dis_score: CNNDiscriminator.forward (models/discriminator.py:40-64) + softmax column
@@ -165,6 +200,7 @@ def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_rewar
     return {"reward": reward, "logits": logits, "feature": feat}
 
 
+@_on_device
 def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout_uniforms=None, reward_out=None,
                       weights=None, precision=None, dropout_seed=None):
     """tg_dis_score_rollout: the scorer over tg_gen_rollout's [R,L,B,L] completions with prefix reuse
@@ -188,6 +224,7 @@ def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout
     return reward
 
 
+@_on_device
 def reward_reduce(raw, B, L, R):
     """tg_reward_reduce: torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153)."""
     if raw.numel() != R * L * B:
@@ -198,6 +235,7 @@ def reward_reduce(raw, B, L, R):
     return out
 
 
+@_on_device
 def dis_rescore_dropout(dis, feature, R, col=1, dropout_p=0.0, dropout_uniforms=None, weights=None,
                         dropout_seed=None):
     """tg_dis_rescore_dropout: R dropout masks + output layer + softmax column over precomputed highway features
