@@ -181,6 +181,22 @@ int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
                   void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * tg_gen_sample without any allocation, by the library or by the caller.
+ * No counterpart in the reference: this entry point exists for callers that cannot allocate device memory -- code
+ * under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc -- and so cannot bring the
+ * `workspace` tg_gen_sample asks for.  Same arguments (minus the workspace), same kernels, same tokens as
+ * tg_gen_sample with TG_GEN_SPLIT_F16 at E = H = 32; the scratch (the split projection's |max| header and W_out
+ * fragments) is a static device array of tg_gen_sample_static_bytes() = 2 621 696 bytes that every GPU the library
+ * runs on holds until the process ends.  Limits: E = H = 32, TG_GEN_SPLIT_F16, V <= TG_STATIC_MAX_V (TG_ERR_ARG with
+ * a message otherwise).  Calls no hipMalloc / hipFree.  All calls on one GPU share that GPU's array: two calls that
+ * overlap on one GPU (different streams, different threads) race -- serialise them. */
+#define TG_STATIC_MAX_V 16384
+size_t tg_gen_sample_static_bytes(void);
+int tg_gen_sample_static(const TgGenWeights* w, int N, int L, int64_t start_letter,
+                         const float* uniforms, const int64_t* forced, int64_t* out,
+                         void* stream);
+
+/* ---------------------------------------------------------------------------
  * CNN discriminator scorer.
  * Replaces CNNDiscriminator.forward / get_feature
  * (models/discriminator.py:40-64) followed by F.softmax(...)[:, col]

@@ -15,6 +15,7 @@ MAX_OUT = 8
 
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
+           "tg_gen_sample_static_bytes", "tg_gen_sample_static",
            "tg_dis_workspace_bytes",
            "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
            "tg_gen_nll_workspace_bytes", "tg_gen_nll", "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
@@ -68,6 +69,11 @@ def lib():
                                                                                                   C.c_void_p]
         l.tg_gen_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_size_t, C.c_void_p]
+        l.tg_gen_sample_static_bytes.restype = C.c_size_t
+        l.tg_gen_sample_static_bytes.argtypes = []
+        l.tg_gen_sample_static.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_void_p]
+        l.tg_gen_sample_static.restype = C.c_int
         l.tg_dis_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5 + \
                                   [C.c_size_t, C.c_void_p]
         l.tg_dis_score_rollout_workspace_bytes.restype = C.c_size_t

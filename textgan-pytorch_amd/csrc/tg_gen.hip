@@ -23,6 +23,8 @@
 //        each wave owns H/32 gate tiles (its c state: H/8 VGPRs).
 #include <stdlib.h>
 
+#include <mutex>
+
 #include <type_traits>
 
 #include "tg_common.h"
@@ -1209,4 +1211,70 @@ extern "C" int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_
         if (rc) return rc;
     }
     return launch<true>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// tg_gen_sample_static: tg_gen_sample for callers that cannot allocate (HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc).  Same kernels as tg_gen_sample with TG_GEN_SPLIT_F16 at E = H = 32; the split projection's
+// scratch (|max| header + W_out fragments, what tg_gen_sample takes as `workspace`) lives in a file-scope device
+// array instead.  Every GPU the library runs on holds its own copy of the array until the process ends; its device
+// address is looked up once per device (hipGetSymbolAddress) and only that pointer is ever handed to kernels or
+// memsets -- the array's name in host code is a host-side stand-in, not a device address.
+namespace {
+constexpr int kStaticMaxV = TG_STATIC_MAX_V;
+constexpr size_t kStaticBytes = 256 + (size_t)4 * ((kStaticMaxV + 127) / 128) * 5 * 64 * sizeof(f32x4);  // split_bytes at kStaticMaxV
+constexpr int kStaticMaxDevices = 64;
+void* g_static_ptr[kStaticMaxDevices] = {};
+std::mutex g_static_mu;
+}  // namespace
+static __device__ __align__(256) unsigned char scratch[kStaticBytes];
+
+// Device address of this device's copy of `scratch` (first call on a device looks it up; no allocation).
+static int static_scratch(void** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kStaticMaxDevices) {
+        tg_set_error("tg_gen_sample_static: hipGetDevice failed or device index %d >= %d", dev, kStaticMaxDevices);
+        return TG_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lk(g_static_mu);
+    if (!g_static_ptr[dev]) {
+        void* p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            tg_set_error("tg_gen_sample_static: hipGetSymbolAddress: %s", hipGetErrorString(e));
+            return TG_ERR_LAUNCH;
+        }
+        g_static_ptr[dev] = p;
+    }
+    *out = g_static_ptr[dev];
+    return TG_OK;
+}
+
+extern "C" size_t tg_gen_sample_static_bytes(void) { return kStaticBytes; }
+
+extern "C" int tg_gen_sample_static(const TgGenWeights* w, int N, int L, int64_t start_letter, const float* uniforms,
+                                    const int64_t* forced, int64_t* out, void* stream) {
+    int rc = check_weights(w);
+    if (rc) return rc;
+    if (!use_split(*w)) {
+        tg_set_error("tg_gen_sample_static: E = H = 32 with TG_GEN_SPLIT_F16 only (got E=%d H=%d precision=%d); "
+                     "TG_GEN_FP32 needs no scratch: call tg_gen_sample with workspace = NULL", w->E, w->H, w->precision);
+        return TG_ERR_ARG;
+    }
+    if (w->V > kStaticMaxV) {
+        tg_set_error("tg_gen_sample_static: vocabulary %d exceeds the static scratch's maximum %d (%zu bytes per GPU); "
+                     "use tg_gen_sample with a caller-provided workspace", w->V, kStaticMaxV, kStaticBytes);
+        return TG_ERR_ARG;
+    }
+    const SamplerGeom geo = make_geom(w->V);
+    if (split_bytes(geo) > kStaticBytes) {  // cannot happen for V <= kStaticMaxV; kept as the guard of the array bound
+        tg_set_error("tg_gen_sample_static: scratch of %zu bytes exceeds the static array (%zu)", split_bytes(geo), kStaticBytes);
+        return TG_ERR_WORKSPACE;
+    }
+    void* ptr = nullptr;
+    rc = static_scratch(&ptr);
+    if (rc) return rc;
+    // prepare_split clears the |max| header (the one part that must start at zero) and rewrites every fragment the
+    // kernel will read for this vocabulary; what an earlier call left behind past them is never read.
+    return tg_gen_sample(w, N, L, start_letter, uniforms, forced, out, ptr, kStaticBytes, stream);
 }
