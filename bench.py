@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """bench.py -- Monte-Carlo rollout completions/s on MI355X (BASELINE.json metric).
 
-A step is one ROLLOUT.get_reward call (prefix states + all completions + CNN scorer with live
-dropout + exchange + reduce) on BASELINE.json configs[1] (SeqGAN real-data shape: vocab 5255,
-len 51, emb/hidden 32, batch 64, rollout_num 16) PER GPU; with N GPUs the call has
-rollout_num 16*N sharded over the ranks by rollout index (weak scaling) and one RCCL
-all-gather of the raw reward rows.  Synthetic weights / tokens (textgan-pytorch_amd/synth.py),
-inputs resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+A step is one ROLLOUT.get_reward call (weight broadcast when sharded + prefix states + all
+completions + CNN scorer with live dropout + exchange + reduce) on BASELINE.json configs[1]
+(SeqGAN real-data shape: vocab 5255, len 51, emb/hidden 32, batch 64, rollout_num 16) PER GPU;
+with N GPUs the call has rollout_num 16*N sharded over the ranks by rollout index (weak
+scaling) and one RCCL all-gather of the raw reward rows.  The same JSON line carries a `scaled`
+sub-record: configs[2]'s shape (vocab 32k, len 51, emb/hidden 512, batch 4096) at rollout_num 8
+IN TOTAL at every N (strong scaling), with its own roofline and cpu_baseline.  Synthetic
+weights / tokens (textgan-pytorch_amd/synth.py), inputs resident in HBM before the timed region.
+Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -29,9 +32,12 @@ WORKLOADS = {
     "c3s": dict(V=32000, L=51, E=512, H=512, B=4096, R=1, desc="configs[2] scaled rollout, 1/64 slice (rollout_num 1 of 64)"),
     "c3": dict(V=32000, L=51, E=512, H=512, B=4096, R=64, strong=True,
                desc="configs[2] scaled rollout, full size (rollout_num 64 in total, sharded over the ranks)"),
+    "c3r8": dict(V=32000, L=51, E=512, H=512, B=4096, R=8, strong=True,
+                 desc="configs[2] scaled rollout shape at rollout_num 8 of 64 (the same total at every --gpus: strong scaling)"),
     "c4": dict(V=5000, L=20, E=32, H=32, B=64, R=16, k=4, dis="sentigan",
                desc="configs[3] SentiGAN k=4 generators, shared 5-way CNN_D, 4 sequential get_reward calls"),
 }
+SCALED = "c3r8"                 # the `scaled` sub-record of the default line
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md, Peak BF16/FP16 MFMA, dense
 
@@ -231,12 +237,148 @@ def bench_pg(args, dev):
     print(json.dumps(out))
 
 
+def run_rollout(args, name, world, rank, dev, steps, warmup):
+    """One completions/s record for WORKLOADS[name]: `warmup` untimed get_reward steps, then exactly `steps` timed ones
+    between barrier + synchronize on both sides, max over ranks.  Returns the record on rank 0, None elsewhere."""
+    wl = WORKLOADS[name]
+    V, L, E, H, B = wl["V"], wl["L"], wl["E"], wl["H"], wl["B"]
+    strong = bool(wl.get("strong"))
+    if strong and wl["R"] % world:
+        raise SystemExit("workload %s shards rollout_num %d over the ranks: --gpus must divide it" % (name, wl["R"]))
+    R = wl["R"] if strong else wl["R"] * world  # weak scaling: rollout_num 16 per GPU; strong: fixed total
+    r_local = R // world                        # rollout indices one rank's launches process
+    k_gens = wl.get("k", 1)
+    std = 1.0 if H == 32 else 0.05   # N(0,1) "oracle" weights (generator.py:97-100); small std at H = 512
+    gens = [tg.modules.synthetic_generator(V, E, H, L, seed=i, std=std, device=dev) for i in range(k_gens)]
+    dis_kind = wl.get("dis", "seqgan")
+    dis = tg.modules.synthetic_discriminator(dis_kind, V, seed=0, k_label=4, device=dev)
+    if args.eval_mode:
+        dis.eval()
+    sent = torch.from_numpy(tg.synth.tokens(1, (B, L), V)).to(dev)
+    ros = []
+    for gi, g in enumerate(gens):
+        ro = tg.ROLLOUT(g, True)
+        ro.generator = torch.Generator(device=dev)
+        ro.generator.manual_seed(1234 + 100 * gi)   # the same seed on every rank: the library derives per-rank streams
+        if world > 1:
+            ro.group = tg.dist.WORLD                # shard the rollout index over the ranks (opt-in); weights are
+            ro.sync_weights = True                  # broadcast from rank 0 at the top of every call (once per step)
+        ro.dis_precision = args.dis_precision
+        ro.gen_precision = args.gen_precision
+        if args.dropout_rng:
+            ro.dropout_rng = args.dropout_rng
+        ros.append(ro)
+
+    def step():
+        # SentiGAN (k generators, shared D): generators are visited sequentially, column current_k + 1
+        # (instructor/real_data/sentigan_instructor.py:137-147)
+        out = None
+        for gi, ro in enumerate(ros):
+            out = ro.get_reward(sent, R, dis, gi if k_gens > 1 else 0)
+        return out
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rewards = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = tg._lib.profile_read()
+    tg._lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert tuple(rewards.shape) == (B, L) and bool(torch.isfinite(rewards).all())
+    del ros, gens, dis, rewards
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+
+    completions = B * R * L * k_gens  # whole job, per step
+    filt = tg.synth.SENTIGAN_D_FILTERS if dis_kind == "sentigan" else tg.synth.SEQGAN_D_FILTERS
+    conv_f, conv_fresh_bi, hw_f, gen_f = flops_model(V, L, E, H, filt, n_out=5 if dis_kind == "sentigan" else 2)
+    n_local = B * r_local * L  # sequences one rank's launches process per get_reward call
+    split = (args.dis_precision or tg._lib.default_dis_precision) == "split_f16"
+    gsplit = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and E == 32 and H == 32
+    gwide = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and not (E == 32 and H == 32)
+    draws = B * r_local * L * (L - 1) // 2            # sampled tokens of one rank's call
+    cell_steps = B * r_local * (L - 1) * (L - 2) // 2  # wide path: rows enter with their prefix state, no cell step
+    # flops one rank EXECUTES per get_reward call, per kernel (prefix-reuse conv: fresh windows only; the
+    # reference-equivalent conv work, every window of every completion, is reported beside it)
+    per_call = {"dis_conv": conv_fresh_bi * B * r_local, "dis_highway": hw_f * n_local,
+                "gen_sample": gen_f * draws, "genw_proj": 2 * H * V * draws,
+                # the cell GEMM executes the W_hh . h part; W_ih . x comes from a per-call table over the vocabulary
+                "genw_cell": 8 * H * H * (cell_steps + B * (L - 1))}
+    f16 = {"dis_conv": split, "dis_highway": split, "gen_sample": gsplit, "genw_proj": True, "genw_cell": True}
+    peaks = {k: PEAK_F16_MFMA_TFLOPS if v else PEAK_FP32_MFMA_TFLOPS for k, v in f16.items()}
+    # split-f16 kernels issue three fp16 MFMA products per algorithmic multiply-add
+    issue_factor = {k: 3 if v else 1 for k, v in f16.items()}
+    kernels = {}
+    calls = steps * k_gens
+    for kname, (ms, n) in prof.items():
+        if n:
+            kernels[kname] = {"avg_ms": ms / n, "launches": n, "ms_per_call": ms / calls}
+            if kname in per_call:
+                kernels[kname]["tflops"] = per_call[kname] * calls / (ms * 1e-3) / 1e12
+                kernels[kname]["peak_tflops"] = peaks[kname]
+                kernels[kname]["mfma_products_per_flop"] = issue_factor[kname]
+    kernels["dis_conv"]["reference_equivalent_tflops"] = conv_f * n_local / (kernels["dis_conv"]["ms_per_call"] * 1e-3) / 1e12
+    per_launch = {k: v * calls / kernels[k]["launches"] for k, v in per_call.items() if k in kernels}
+    dom = max(per_launch, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
+    ach = kernels[dom]["tflops"]
+    out = {
+        "metric": "MC rollout completions/sec", "value": completions * steps / dt, "unit": "completions/s",
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": dt / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
+        "dtype": "f32" + (" (split-f16 x3 operands, f32 accumulate: %s)" % ", ".join(
+            (["generator projection"] if gsplit else []) + (["generator gates and projection"] if gwide else []) +
+            (["scorer conv/highway"] if split else []))
+            if (split or gsplit or gwide) else ""), "data": "synthetic",
+        "config": {"workload": "%s: vocab %d, len %d, emb/hidden %d, batch %d, rollout_num %d per GPU (%d total), "
+                               "%s scorer%s" % (wl["desc"], V, L, H, B, r_local, R, dis_kind,
+                                                " eval mode" if args.eval_mode else " with live dropout"),
+                   "completions_per_step": completions,
+                   "sharding": "rollout index over %d rank(s)%s" % (
+                       world, ", weights broadcast from rank 0 once per step, one all-gather of the raw rows" if world > 1 else "")},
+        "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peaks[dom],
+                     "unit": "TFLOP/s", "frac": ach / peaks[dom],
+                     "traffic": pmc_traffic(name, dom) if world == 1 else None,
+                     "flops_per_launch": per_launch[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
+                     # split-f16 kernels issue 3 fp16 MFMA products per algorithmic multiply-add: the share of the
+                     # fp16 peak the matrix pipes actually deliver (DESIGN.md 3.2: the kernel is power-limited)
+                     "mfma_products_per_flop": issue_factor[dom],
+                     "issued_frac": ach * issue_factor[dom] / peaks[dom]},
+        "kernels": kernels,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(wl)
+    elif world == 1:
+        out["cpu_baseline"] = None
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS) + ["c5", "pg"])
+    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["c5", "pg"],
+                    help="default: the headline line on configs[1] (c2, weak scaling over --gpus) carrying a `scaled` "
+                         "sub-record on configs[2]'s shape (c3r8, strong scaling over --gpus); any other name: that "
+                         "workload alone")
+    ap.add_argument("--scaled-steps", type=int, default=None, help="timed steps of the `scaled` sub-record (default: --steps)")
+    ap.add_argument("--scaled-warmup", type=int, default=None, help="warm-up steps of the `scaled` sub-record (default: --warmup)")
+    ap.add_argument("--no-scaled", action="store_true", help="default workload without the `scaled` sub-record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
     ap.add_argument("--dis-precision", default=None, choices=["fp32", "split_f16"],
@@ -267,124 +409,20 @@ def main():
         if world > 1:
             raise SystemExit("workload pg (policy-gradient step) is a single-GPU side measurement")
         return bench_pg(args, dev)
-    wl = WORKLOADS[args.workload]
-    V, L, E, H, B = wl["V"], wl["L"], wl["E"], wl["H"], wl["B"]
-    strong = bool(wl.get("strong"))
-    if strong and wl["R"] % world:
-        raise SystemExit("workload %s shards rollout_num %d over the ranks: --gpus must divide it" % (args.workload, wl["R"]))
-    R = wl["R"] if strong else wl["R"] * world  # weak scaling: rollout_num 16 per GPU; c3: 64 in total
-    r_local = R // world                        # rollout indices one rank's launches process
-    k_gens = wl.get("k", 1)
-    std = 1.0 if H == 32 else 0.05   # N(0,1) "oracle" weights (generator.py:97-100); small std at H = 512
-    gens = [tg.modules.synthetic_generator(V, E, H, L, seed=i, std=std, device=dev) for i in range(k_gens)]
-    dis_kind = wl.get("dis", "seqgan")
-    dis = tg.modules.synthetic_discriminator(dis_kind, V, seed=0, k_label=4, device=dev)
-    if args.eval_mode:
-        dis.eval()
-    sent = torch.from_numpy(tg.synth.tokens(1, (B, L), V)).to(dev)
-    ros = []
-    for gi, g in enumerate(gens):
-        ro = tg.ROLLOUT(g, True)
-        ro.generator = torch.Generator(device=dev)
-        ro.generator.manual_seed(1234 + rank + 100 * gi)
-        ro.dis_precision = args.dis_precision
-        ro.gen_precision = args.gen_precision
-        if args.dropout_rng:
-            ro.dropout_rng = args.dropout_rng
-        ros.append(ro)
-
-    def step():
-        # SentiGAN (k generators, shared D): generators are visited sequentially, column current_k + 1
-        # (instructor/real_data/sentigan_instructor.py:137-147)
-        out = None
-        for gi, ro in enumerate(ros):
-            out = ro.get_reward(sent, R, dis, gi if k_gens > 1 else 0)
-        return out
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    tg._lib.profile_enable(True)
-    tg._lib.profile_read()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rewards = step()
-    barrier()
-    dt = time.perf_counter() - t0
-    prof = tg._lib.profile_read()
-    tg._lib.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert tuple(rewards.shape) == (B, L) and bool(torch.isfinite(rewards).all())
-
+    if args.workload != "default":
+        out = run_rollout(args, args.workload, world, rank, dev, args.steps, args.warmup)
+    else:
+        # the headline: configs[1], rollout_num 16 per GPU (weak scaling) ...
+        out = run_rollout(args, "c2", world, rank, dev, args.steps, args.warmup)
+        # ... and, in the same line, configs[2]'s shape at a rollout_num one GPU finishes in seconds per step, the same
+        # TOTAL work at every --gpus (strong scaling, what BASELINE.json asks of configs[2] at 1/2/4/8 GPUs)
+        if not args.no_scaled and WORKLOADS[SCALED]["R"] % world == 0:
+            sub = run_rollout(args, SCALED, world, rank, dev,
+                              args.steps if args.scaled_steps is None else args.scaled_steps,
+                              args.warmup if args.scaled_warmup is None else args.scaled_warmup)
+            if rank == 0:
+                out["scaled"] = sub
     if rank == 0:
-        completions = B * R * L * k_gens  # whole job, per step
-        filt = tg.synth.SENTIGAN_D_FILTERS if dis_kind == "sentigan" else tg.synth.SEQGAN_D_FILTERS
-        conv_f, conv_fresh_bi, hw_f, gen_f = flops_model(V, L, E, H, filt, n_out=dis.feature2out.out_features)
-        n_local = B * r_local * L  # sequences one rank's launches process per get_reward call
-        split = (args.dis_precision or tg._lib.default_dis_precision) == "split_f16"
-        gsplit = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and E == 32 and H == 32
-        # flops one launch EXECUTES (prefix-reuse conv: fresh windows only); the reference-equivalent conv work
-        # (every window of every completion) is reported beside it
-        gwide = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16" and not (E == 32 and H == 32)
-        draws = B * r_local * L * (L - 1) // 2            # sampled tokens of one rank's call
-        cell_steps = B * r_local * (L - 1) * (L - 2) // 2  # wide path: rows enter with their prefix state, no cell step
-        # flops one rank EXECUTES per get_reward call, per kernel (prefix-reuse conv: fresh windows only; the
-        # reference-equivalent conv work, every window of every completion, is reported beside it)
-        per_call = {"dis_conv": conv_fresh_bi * B * r_local, "dis_highway": hw_f * n_local,
-                    "gen_sample": gen_f * draws, "genw_proj": 2 * H * V * draws,
-                    # the cell GEMM executes the W_hh . h part; W_ih . x comes from a per-call table over the vocabulary
-                    "genw_cell": 8 * H * H * (cell_steps + B * (L - 1))}
-        f16 = {"dis_conv": split, "dis_highway": split, "gen_sample": gsplit, "genw_proj": True, "genw_cell": True}
-        peaks = {k: PEAK_F16_MFMA_TFLOPS if v else PEAK_FP32_MFMA_TFLOPS for k, v in f16.items()}
-        # split-f16 kernels issue three fp16 MFMA products per algorithmic multiply-add
-        issue_factor = {k: 3 if v else 1 for k, v in f16.items()}
-        kernels = {}
-        calls = args.steps * k_gens
-        for name, (ms, n) in prof.items():
-            if n:
-                kernels[name] = {"avg_ms": ms / n, "launches": n, "ms_per_call": ms / calls}
-                if name in per_call:
-                    kernels[name]["tflops"] = per_call[name] * calls / (ms * 1e-3) / 1e12
-                    kernels[name]["peak_tflops"] = peaks[name]
-                    kernels[name]["mfma_products_per_flop"] = issue_factor[name]
-        kernels["dis_conv"]["reference_equivalent_tflops"] = conv_f * n_local / (kernels["dis_conv"]["ms_per_call"] * 1e-3) / 1e12
-        per_launch = {k: v * calls / kernels[k]["launches"] for k, v in per_call.items() if k in kernels}
-        dom = max(per_launch, key=lambda k: kernels[k]["avg_ms"] * kernels[k]["launches"])
-        ach = kernels[dom]["tflops"]
-        out = {
-            "metric": "MC rollout completions/sec", "value": completions * args.steps / dt, "unit": "completions/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "f32" + (" (split-f16 x3 operands, f32 accumulate: %s)" % ", ".join(
-                (["generator projection"] if gsplit else []) + (["generator gates and projection"] if gwide else []) +
-                (["scorer conv/highway"] if split else []))
-                if (split or gsplit or gwide) else ""), "data": "synthetic",
-            "config": {"workload": "%s: vocab %d, len %d, emb/hidden %d, batch %d, rollout_num %d per GPU (%d total), "
-                                   "%s scorer%s" % (wl["desc"], V, L, H, B, r_local, R, dis_kind,
-                                                    " eval mode" if args.eval_mode else " with live dropout"),
-                       "completions_per_step": completions, "sharding": "rollout index over %d rank(s)" % world},
-            "roofline": {"kernel": dom, "bound": "mfma", "achieved": ach, "peak": peaks[dom],
-                         "unit": "TFLOP/s", "frac": ach / peaks[dom],
-                         "traffic": pmc_traffic(args.workload, dom) if world == 1 else None,
-                         "flops_per_launch": per_launch[dom], "avg_launch_ms": kernels[dom]["avg_ms"],
-                         # split-f16 kernels issue 3 fp16 MFMA products per algorithmic multiply-add: the share of the
-                         # fp16 peak the matrix pipes actually deliver (the kernel is power-limited)
-                         "mfma_products_per_flop": issue_factor[dom],
-                         "issued_frac": ach * issue_factor[dom] / peaks[dom]},
-            "kernels": kernels,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(wl)
-        elif world == 1:
-            out["cpu_baseline"] = None
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
