@@ -36,6 +36,12 @@ class DisW(C.Structure):
                 ("V", C.c_int32), ("Ed", C.c_int32), ("F", C.c_int32), ("n_out", C.c_int32), ("precision", C.c_int32)]
 
 
+class LeakW(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in ("emb", "w_wih", "w_whh", "w_bih", "w_bhh", "m_wih", "m_whh", "m_bih", "m_bhh",
+                                          "w2g_w", "w2g_b", "m2g_w", "m2g_b", "g2g_w", "goal_init")] + \
+               [(k, C.c_int32) for k in ("V", "E", "H", "G", "K", "step_size", "B_init", "_pad")]
+
+
 _lib = None
 
 
@@ -50,6 +56,9 @@ def lib():
         _lib.orc_num_threads.restype = C.c_int
         _lib.orc_dis_forward.restype = C.c_int
         _lib.orc_get_reward.restype = C.c_int
+        _lib.orc_leak_rollout.restype = C.c_int
+        _lib.orc_get_reward_leakgan.restype = C.c_int
+        _lib.orc_leak_logits_at.restype = C.c_int
     return _lib
 
 
@@ -105,6 +114,25 @@ class Dis:
         self.n_out = self.keep[-1].shape[0]
         w.V, w.Ed, w.F, w.n_out = self.V, self.Ed, F, self.n_out
         self.w = w
+
+
+class Leak:
+    """Holds fp32 copies of a LeakGAN_G state_dict (models/LeakGAN_G.py:40-48) and its step_size."""
+
+    KEYS = ("embeddings.weight", "worker.weight_ih_l0", "worker.weight_hh_l0", "worker.bias_ih_l0", "worker.bias_hh_l0",
+            "manager.weight_ih_l0", "manager.weight_hh_l0", "manager.bias_ih_l0", "manager.bias_hh_l0",
+            "work2goal.weight", "work2goal.bias", "mana2goal.weight", "mana2goal.bias", "goal2goal.weight", "goal_init")
+
+    def __init__(self, sd, step_size=4):
+        self.a = [_f32(np.asarray(sd[k])) for k in self.KEYS]
+        self.V, self.E = self.a[0].shape
+        self.H = self.a[2].shape[1]
+        self.K, self.G = self.a[13].shape
+        self.B_init = self.a[14].shape[0]
+        self.step_size = int(step_size)
+        assert self.a[9].shape == (self.V * self.K, self.H) and self.a[5].shape == (4 * self.H, self.G)
+        self.w = LeakW(*[x.ctypes.data for x in self.a], self.V, self.E, self.H, self.G, self.K, self.step_size,
+                       self.B_init, 0)
 
 
 def num_threads():
@@ -197,6 +225,55 @@ def get_reward(gen, dis, sentences, R, uniforms, col=1, dropout_p=0.0, dropout_u
                               C.c_float(dropout_p), _p(du), _p(comp), _p(raw), _p(out))
     if rc:
         raise RuntimeError("oracle: sequence length %d shorter than a filter width" % L)
+    return {"completions": comp, "raw": raw, "reward": out}
+
+
+def leak_rollout(gen, dis, sentences, R, uniforms, i_lo=0, i_hi=None, forced=None):
+    """ROLLOUT.rollout_mc_search_leakgan for every (rollout, t) of get_reward_leakgan (utils/rollout.py:57-126,172-175).
+    uniforms [R,T,L,B]; returns completions [R,T,B,L] (T = L // step_size, given_num = t*step_size + 1)."""
+    s = _i64(sentences)
+    B, L = s.shape
+    T = L // gen.step_size
+    i_hi = R if i_hi is None else i_hi
+    u = _f32(uniforms)
+    assert u.size == R * T * L * B
+    comp = np.zeros((R, T, B, L), np.int64)
+    f = None if forced is None else _i64(forced)
+    rc = lib().orc_leak_rollout(C.byref(gen.w), C.byref(dis.w), _p(s), B, L, R, i_lo, i_hi, _p(u), _p(f), _p(comp))
+    if rc:
+        raise RuntimeError("oracle: leak_rollout rejected its arguments (%d)" % rc)
+    return comp
+
+
+def leak_logits_at(gen, dis, tokens, b, pos):
+    """Outputs of LeakGAN_G.forward (temperature-scaled, before log_softmax) after feeding tokens[0..pos] of a row
+    whose goal_init row is b: the distribution position pos+1 is drawn from."""
+    t = _i64(tokens)
+    out = np.empty(gen.V, np.float32)
+    rc = lib().orc_leak_logits_at(C.byref(gen.w), C.byref(dis.w), _p(t), int(b), t.shape[0], int(pos), _p(out))
+    if rc:
+        raise RuntimeError("oracle: leak_logits_at rejected its arguments (%d)" % rc)
+    return out
+
+
+def get_reward_leakgan(gen, dis, sentences, R, uniforms, col=1, dropout_p=0.0, dropout_uniforms=None,
+                       i_lo=0, i_hi=None, reduce=True):
+    """ROLLOUT.get_reward_leakgan (utils/rollout.py:156-184).  Returns dict(completions [R,T,B,L], raw [R*T,B],
+    reward [B,T])."""
+    s = _i64(sentences)
+    B, L = s.shape
+    T = L // gen.step_size
+    i_hi = R if i_hi is None else i_hi
+    u = _f32(uniforms)
+    assert u.size == R * T * L * B
+    du = None if dropout_uniforms is None else _f32(dropout_uniforms)
+    comp = np.zeros((R, T, B, L), np.int64)
+    raw = np.zeros((R * T, B), np.float32)
+    out = np.empty((B, T), np.float32) if reduce else None
+    rc = lib().orc_get_reward_leakgan(C.byref(gen.w), C.byref(dis.w), _p(s), B, L, R, i_lo, i_hi, col, _p(u),
+                                      C.c_float(dropout_p), _p(du), _p(comp), _p(raw), _p(out))
+    if rc:
+        raise RuntimeError("oracle: get_reward_leakgan rejected its arguments (%d)" % rc)
     return {"completions": comp, "raw": raw, "reward": out}
 
 

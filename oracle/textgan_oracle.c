@@ -421,22 +421,74 @@ void orc_gen_sample(const OrcGenWeights* w, int N, int L, int64_t start_letter,
  * get_feature value, before dropout), reward_out [N] = softmax(logits)[col]
  * (utils/rollout.py:147-148).  Returns -1 if L < max filter width (the
  * reference raises RuntimeError from conv2d). */
+
+/* Transposed scorer weights (conv [f*Ed][n_k], highway [F_in][F_out]) so the inner loops run over the output
+ * index and vectorise without reassociating the k-sums. */
+typedef struct DisT {
+    float* cw_t[ORC_MAX_FILTERS];
+    float* hw_t;
+} DisT;
+
+static void dis_t_init(DisT* t, const OrcDisWeights* w) {
+    const int Ed = w->Ed, F = w->F, nf = w->n_filters;
+    for (int k = 0; k < nf; ++k) {
+        const int K = w->f[k] * Ed, n = w->n[k];
+        t->cw_t[k] = (float*)malloc(sizeof(float) * (size_t)K * n);
+        for (int m = 0; m < n; ++m)
+            for (int kk = 0; kk < K; ++kk) t->cw_t[k][(size_t)kk * n + m] = w->conv_w[k][(size_t)m * K + kk];
+    }
+    t->hw_t = (float*)malloc(sizeof(float) * (size_t)F * F);
+    for (int o = 0; o < F; ++o)
+        for (int i = 0; i < F; ++i) t->hw_t[(size_t)i * F + o] = w->hw_w[(size_t)o * F + i];
+}
+static void dis_t_free(DisT* t, const OrcDisWeights* w) {
+    for (int k = 0; k < w->n_filters; ++k) free(t->cw_t[k]);
+    free(t->hw_t);
+}
+
+/* CNNDiscriminator.get_feature for one sequence (models/discriminator.py:51-64): embedding gather, per width
+ * Conv2d + ReLU + max over time, concat, highway.  e [L*Ed], pooled [F], acc [1024] are scratch; hwy [F] is the
+ * feature (before dropout). */
+static void dis_feature_row(const OrcDisWeights* w, const DisT* t, const int64_t* seq, int L, float* e, float* pooled,
+                            float* acc, float* hwy) {
+    const int Ed = w->Ed, F = w->F, nf = w->n_filters;
+    for (int s = 0; s < L; ++s) memcpy(e + (size_t)s * Ed, w->emb + (size_t)seq[s] * Ed, sizeof(float) * Ed);
+    int off = 0;
+    for (int k = 0; k < nf; ++k) {
+        const int f = w->f[k], nk = w->n[k], K = f * Ed, T = L - f + 1;
+        for (int m = 0; m < nk; ++m) pooled[off + m] = 0.f; /* relu floor */
+        for (int tt = 0; tt < T; ++tt) {
+            const float* x = e + (size_t)tt * Ed; /* window = K contiguous floats */
+            for (int m = 0; m < nk; ++m) acc[m] = w->conv_b[k][m];
+            for (int kk = 0; kk < K; ++kk) {
+                const float xv = x[kk];
+                const float* wr = t->cw_t[k] + (size_t)kk * nk;
+                for (int m = 0; m < nk; ++m) acc[m] += wr[m] * xv;
+            }
+            for (int m = 0; m < nk; ++m) pooled[off + m] = acc[m] > pooled[off + m] ? acc[m] : pooled[off + m];
+        }
+        off += nk;
+    }
+    /* highway: sigmoid(h)*relu(h) + (1-sigmoid(h))*pred  (discriminator.py:61-62) */
+    for (int o = 0; o < F; ++o) hwy[o] = w->hw_b[o];
+    for (int i = 0; i < F; ++i) {
+        const float pv = pooled[i];
+        const float* wr = t->hw_t + (size_t)i * F;
+        for (int o = 0; o < F; ++o) hwy[o] += wr[o] * pv;
+    }
+    for (int o = 0; o < F; ++o) {
+        const float sg = sigmoidf_(hwy[o]);
+        const float rl = hwy[o] > 0.f ? hwy[o] : 0.f;
+        hwy[o] = sg * rl + (1.f - sg) * pooled[o];
+    }
+}
+
 int orc_dis_forward(const OrcDisWeights* w, const int64_t* seqs, int N, int L, int col,
                     float dropout_p, const float* dropout_uniforms,
                     float* reward_out, float* logits_out, float* feature_out) {
     const int Ed = w->Ed, F = w->F, nf = w->n_filters, n_out = w->n_out;
     for (int k = 0; k < nf; ++k) if (w->f[k] > L) return -1;
-    /* transposed weights: conv [f*Ed][n_k], highway [F_in][F_out] */
-    float* cw_t[ORC_MAX_FILTERS];
-    for (int k = 0; k < nf; ++k) {
-        const int K = w->f[k] * Ed, n = w->n[k];
-        cw_t[k] = (float*)malloc(sizeof(float) * (size_t)K * n);
-        for (int m = 0; m < n; ++m)
-            for (int kk = 0; kk < K; ++kk) cw_t[k][(size_t)kk * n + m] = w->conv_w[k][(size_t)m * K + kk];
-    }
-    float* hw_t = (float*)malloc(sizeof(float) * (size_t)F * F);
-    for (int o = 0; o < F; ++o)
-        for (int i = 0; i < F; ++i) hw_t[(size_t)i * F + o] = w->hw_w[(size_t)o * F + i];
+    DisT t; dis_t_init(&t, w);
     const float keep_scale = (dropout_p > 0.f) ? 1.f / (1.f - dropout_p) : 1.f;
 #pragma omp parallel
     {
@@ -446,36 +498,7 @@ int orc_dis_forward(const OrcDisWeights* w, const int64_t* seqs, int N, int L, i
         float* acc = (float*)malloc(sizeof(float) * 1024);
 #pragma omp for schedule(dynamic, 8)
         for (int n = 0; n < N; ++n) {
-            for (int s = 0; s < L; ++s)
-                memcpy(e + (size_t)s * Ed, w->emb + (size_t)seqs[(size_t)n * L + s] * Ed, sizeof(float) * Ed);
-            int off = 0;
-            for (int k = 0; k < nf; ++k) {
-                const int f = w->f[k], nk = w->n[k], K = f * Ed, T = L - f + 1;
-                for (int m = 0; m < nk; ++m) pooled[off + m] = 0.f; /* relu floor */
-                for (int tt = 0; tt < T; ++tt) {
-                    const float* x = e + (size_t)tt * Ed; /* window = K contiguous floats */
-                    for (int m = 0; m < nk; ++m) acc[m] = w->conv_b[k][m];
-                    for (int kk = 0; kk < K; ++kk) {
-                        const float xv = x[kk];
-                        const float* wr = cw_t[k] + (size_t)kk * nk;
-                        for (int m = 0; m < nk; ++m) acc[m] += wr[m] * xv;
-                    }
-                    for (int m = 0; m < nk; ++m) pooled[off + m] = acc[m] > pooled[off + m] ? acc[m] : pooled[off + m];
-                }
-                off += nk;
-            }
-            /* highway: sigmoid(h)*relu(h) + (1-sigmoid(h))*pred  (discriminator.py:61-62) */
-            for (int o = 0; o < F; ++o) hwy[o] = w->hw_b[o];
-            for (int i = 0; i < F; ++i) {
-                const float pv = pooled[i];
-                const float* wr = hw_t + (size_t)i * F;
-                for (int o = 0; o < F; ++o) hwy[o] += wr[o] * pv;
-            }
-            for (int o = 0; o < F; ++o) {
-                const float sg = sigmoidf_(hwy[o]);
-                const float rl = hwy[o] > 0.f ? hwy[o] : 0.f;
-                hwy[o] = sg * rl + (1.f - sg) * pooled[o];
-            }
+            dis_feature_row(w, &t, seqs + (size_t)n * L, L, e, pooled, acc, hwy);
             if (feature_out) memcpy(feature_out + (size_t)n * F, hwy, sizeof(float) * F);
             if (dropout_p > 0.f && dropout_uniforms) {
                 const float* du = dropout_uniforms + (size_t)n * F;
@@ -499,8 +522,7 @@ int orc_dis_forward(const OrcDisWeights* w, const int64_t* seqs, int N, int L, i
         }
         free(e); free(pooled); free(hwy); free(acc);
     }
-    for (int k = 0; k < nf; ++k) free(cw_t[k]);
-    free(hw_t);
+    dis_t_free(&t, w);
     return 0;
 }
 
@@ -530,5 +552,290 @@ int orc_get_reward(const OrcGenWeights* g, const OrcDisWeights* d, const int64_t
                              raw + row0, NULL, NULL);
     if (rc) return rc;
     if (out) orc_reward_reduce(raw, B, L, R, out);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------ */
+/* LeakGAN rollout                                         */
+
+/* LeakGAN_G parameters (models/LeakGAN_G.py:40-48; state_dict keys embeddings.weight, worker.*_l0, manager.*_l0,
+ * work2goal.*, mana2goal.*, goal2goal.weight, goal_init).  G = goal_out_size = the scorer's feature width F,
+ * K = goal_size. */
+typedef struct OrcLeakWeights {
+    const float* emb;      /* [V,E]                                   */
+    const float* w_wih;    /* worker.weight_ih_l0   [4H,E]            */
+    const float* w_whh;    /* worker.weight_hh_l0   [4H,H]            */
+    const float* w_bih;    /* [4H] */
+    const float* w_bhh;    /* [4H] */
+    const float* m_wih;    /* manager.weight_ih_l0  [4H,G]            */
+    const float* m_whh;    /* manager.weight_hh_l0  [4H,H]            */
+    const float* m_bih;    /* [4H] */
+    const float* m_bhh;    /* [4H] */
+    const float* w2g_w;    /* work2goal.weight      [V*K,H]           */
+    const float* w2g_b;    /* work2goal.bias        [V*K]             */
+    const float* m2g_w;    /* mana2goal.weight      [G,H]             */
+    const float* m2g_b;    /* mana2goal.bias        [G]               */
+    const float* g2g_w;    /* goal2goal.weight      [K,G] (no bias)   */
+    const float* goal_init;/* goal_init             [B_init,G]        */
+    int32_t V, E, H, G, K, step_size, B_init, _pad;
+} OrcLeakWeights;
+
+/* nn.LSTM cell on an input vector x [nin] (gates i,f,g,o; b_ih + b_hh), transposed weights wih_t [nin][4H],
+ * whh_t [H][4H], bsum [4H].  Same arithmetic order as lstm_cell above. */
+static void lstm_cell_vec(const float* wih_t, const float* whh_t, const float* bsum, int nin, int H, const float* x,
+                          float* h, float* c, float* gates) {
+    const int G4 = 4 * H;
+    for (int r = 0; r < G4; ++r) gates[r] = bsum[r];
+    for (int k = 0; k < nin; ++k) {
+        const float xv = x[k];
+        const float* wr = wih_t + (size_t)k * G4;
+        for (int r = 0; r < G4; ++r) gates[r] += wr[r] * xv;
+    }
+    for (int k = 0; k < H; ++k) {
+        const float hv = h[k];
+        const float* wr = whh_t + (size_t)k * G4;
+        for (int r = 0; r < G4; ++r) gates[r] += wr[r] * hv;
+    }
+    for (int j = 0; j < H; ++j) {
+        const float ig = sigmoidf_(gates[j]);
+        const float fg = sigmoidf_(gates[H + j]);
+        const float gg = tanhf(gates[2 * H + j]);
+        const float og = sigmoidf_(gates[3 * H + j]);
+        const float cn = fg * c[j] + ig * gg;
+        c[j] = cn;
+        h[j] = og * tanhf(cn);
+    }
+}
+
+static float* transpose_new(const float* a, int rows, int cols) { /* [rows][cols] -> [cols][rows] */
+    float* t = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+    for (int r = 0; r < rows; ++r)
+        for (int c = 0; c < cols; ++c) t[(size_t)c * rows + r] = a[(size_t)r * cols + c];
+    return t;
+}
+
+/* F.normalize(x, p=2, dim=-1): x / max(||x||_2, 1e-12) (LeakGAN_G.py:74,76). */
+static void l2_normalize(float* x, int n) {
+    float ss = 0.f;
+    for (int i = 0; i < n; ++i) ss += x[i] * x[i];
+    float nrm = sqrtf(ss);
+    if (nrm < 1e-12f) nrm = 1e-12f;
+    for (int i = 0; i < n; ++i) x[i] = x[i] / nrm;
+}
+
+typedef struct LeakCtx {
+    const OrcLeakWeights* w;
+    const OrcDisWeights* d;
+    DisT dt;
+    float *w_wih_t, *w_whh_t, *m_wih_t, *m_whh_t, *w2g_t, *m2g_t, *w_bsum, *m_bsum;
+} LeakCtx;
+
+static void leak_ctx_init(LeakCtx* c, const OrcLeakWeights* w, const OrcDisWeights* d) {
+    const int V = w->V, E = w->E, H = w->H, G = w->G, K = w->K;
+    c->w = w; c->d = d;
+    dis_t_init(&c->dt, d);
+    c->w_wih_t = transpose_new(w->w_wih, 4 * H, E);
+    c->w_whh_t = transpose_new(w->w_whh, 4 * H, H);
+    c->m_wih_t = transpose_new(w->m_wih, 4 * H, G);
+    c->m_whh_t = transpose_new(w->m_whh, 4 * H, H);
+    c->w2g_t = transpose_new(w->w2g_w, V * K, H);   /* [H][V*K] */
+    c->m2g_t = transpose_new(w->m2g_w, G, H);       /* [H][G]   */
+    c->w_bsum = (float*)malloc(sizeof(float) * 4 * H);
+    c->m_bsum = (float*)malloc(sizeof(float) * 4 * H);
+    for (int r = 0; r < 4 * H; ++r) { c->w_bsum[r] = w->w_bih[r] + w->w_bhh[r]; c->m_bsum[r] = w->m_bih[r] + w->m_bhh[r]; }
+}
+static void leak_ctx_free(LeakCtx* c) {
+    free(c->w_wih_t); free(c->w_whh_t); free(c->m_wih_t); free(c->m_whh_t); free(c->w2g_t); free(c->m2g_t);
+    free(c->w_bsum); free(c->m_bsum);
+    dis_t_free(&c->dt, c->d);
+}
+
+typedef struct LeakScratch {
+    float *e, *pooled, *acc, *feat, *hw, *cw, *hm, *cm, *gates, *goals, *real_goal, *rg, *wo, *logits, *wts;
+    int64_t* fed;
+} LeakScratch;
+
+static void leak_scratch_init(LeakScratch* s, const LeakCtx* c, int L) {
+    const OrcLeakWeights* w = c->w;
+    const int V = w->V, H = w->H, G = w->G, K = w->K;
+    s->e = (float*)malloc(sizeof(float) * (size_t)L * c->d->Ed);
+    s->pooled = (float*)malloc(sizeof(float) * G);
+    s->acc = (float*)malloc(sizeof(float) * 1024);
+    s->feat = (float*)malloc(sizeof(float) * G);
+    s->hw = (float*)malloc(sizeof(float) * H); s->cw = (float*)malloc(sizeof(float) * H);
+    s->hm = (float*)malloc(sizeof(float) * H); s->cm = (float*)malloc(sizeof(float) * H);
+    s->gates = (float*)malloc(sizeof(float) * 4 * H);
+    s->goals = (float*)malloc(sizeof(float) * (size_t)(L + 1) * G);  /* goal_array of one row */
+    s->real_goal = (float*)malloc(sizeof(float) * G);
+    s->rg = (float*)malloc(sizeof(float) * K);
+    s->wo = (float*)malloc(sizeof(float) * (size_t)V * K);
+    s->logits = (float*)malloc(sizeof(float) * V);
+    s->wts = (float*)malloc(sizeof(float) * V);
+    s->fed = (int64_t*)malloc(sizeof(int64_t) * L);
+}
+static void leak_scratch_free(LeakScratch* s) {
+    free(s->e); free(s->pooled); free(s->acc); free(s->feat); free(s->hw); free(s->cw); free(s->hm); free(s->cm);
+    free(s->gates); free(s->goals); free(s->real_goal); free(s->rg); free(s->wo); free(s->logits); free(s->wts); free(s->fed);
+}
+
+/* One row of rollout_mc_search_leakgan: sentence `sent` [L] (tokens < given are copied), goal_init row b.
+ * u: the row's uniforms, u[pos * u_stride]; forced [L] or NULL; out [L].  If probe_logits != NULL the (temperature-
+ * scaled, pre-log_softmax) outputs of position probe_pos are copied there and the row stops. */
+static void leak_row(const LeakCtx* c, LeakScratch* s, const int64_t* sent, int b, int L, int given, const float* u,
+                     size_t u_stride, const int64_t* forced, int64_t* out, int probe_pos, float* probe_logits) {
+    const OrcLeakWeights* w = c->w;
+    const int V = w->V, E = w->E, H = w->H, G = w->G, K = w->K, step = w->step_size;
+    memset(s->hw, 0, sizeof(float) * H); memset(s->cw, 0, sizeof(float) * H);
+    memset(s->hm, 0, sizeof(float) * H); memset(s->cm, 0, sizeof(float) * H);
+    memset(s->goals, 0, sizeof(float) * (size_t)(L + 1) * G);
+    memcpy(s->real_goal, w->goal_init + (size_t)b * G, sizeof(float) * G);
+    memset(s->fed, 0, sizeof(int64_t) * L);   /* zero padding of the feature extractor's input */
+    for (int pos = 0; pos < L; ++pos) {
+        int64_t tok;
+        if (pos < given) {
+            tok = sent[pos];
+            if (out) out[pos] = tok;
+        } else {
+            exp_weights(s->logits, V, s->wts);  /* exp(log_softmax) up to the normaliser (rollout.py:101) */
+            tok = canonical_draw(s->wts, V, u[(size_t)pos * u_stride]);
+            if (out) out[pos] = tok;
+            if (forced) tok = forced[pos];
+        }
+        s->fed[pos] = tok;
+        if (pos == L - 1) break;            /* the reference's last forward is never read */
+        dis_feature_row(c->d, &c->dt, s->fed, L, s->e, s->pooled, s->acc, s->feat);
+        /* manager (LeakGAN_G.py:72-74) */
+        lstm_cell_vec(c->m_wih_t, c->m_whh_t, c->m_bsum, G, H, s->feat, s->hm, s->cm, s->gates);
+        float* cur = s->goals + (size_t)pos * G;
+        for (int o = 0; o < G; ++o) cur[o] = w->m2g_b[o];
+        for (int k = 0; k < H; ++k) {
+            const float hv = s->hm[k];
+            const float* wr = c->m2g_t + (size_t)k * G;
+            for (int o = 0; o < G; ++o) cur[o] += wr[o] * hv;
+        }
+        l2_normalize(cur, G);
+        /* goal2goal on the real goal in force BEFORE this step's update (LeakGAN_G.py:75-76) */
+        for (int k = 0; k < K; ++k) {
+            float a = 0.f;
+            const float* wr = w->g2g_w + (size_t)k * G;
+            for (int o = 0; o < G; ++o) a += wr[o] * s->real_goal[o];
+            s->rg[k] = a;
+        }
+        l2_normalize(s->rg, K);
+        /* worker (LeakGAN_G.py:79-84) */
+        lstm_cell_vec(c->w_wih_t, c->w_whh_t, c->w_bsum, E, H, w->emb + (size_t)tok * E, s->hw, s->cw, s->gates);
+        const size_t VK = (size_t)V * K;
+        for (size_t q = 0; q < VK; ++q) s->wo[q] = w->w2g_b[q];
+        for (int k = 0; k < H; ++k) {
+            const float hv = s->hw[k];
+            const float* wr = c->w2g_t + (size_t)k * VK;
+            for (size_t q = 0; q < VK; ++q) s->wo[q] += wr[q] * hv;
+        }
+        const float temperature = (pos > 1) ? 1.0f : 1.5f;   /* train=True (LeakGAN_G.py:87-95) */
+        for (int v = 0; v < V; ++v) {
+            float a = 0.f;
+            const float* wr = s->wo + (size_t)v * K;
+            for (int k = 0; k < K; ++k) a += wr[k] * s->rg[k];
+            s->logits[v] = temperature * a;
+        }
+        if (probe_logits && pos == probe_pos) {
+            memcpy(probe_logits, s->logits, sizeof(float) * V);
+            return;
+        }
+        /* goal bookkeeping (rollout.py:89-93 / 117-121): the hard-coded window of 4 goals is the reference's */
+        if (pos > 0 && pos % step == 0) {
+            /* goal_array[:, pos-3:pos+1]: for pos < 3 (step_size < 3) the negative start makes the Python slice
+             * EMPTY (it counts from the end of the L+1 axis), so the sum is zero */
+            for (int o = 0; o < G; ++o) {
+                float a = 0.f;
+                if (pos >= 3)
+                    for (int j = pos - 3; j <= pos; ++j) a += s->goals[(size_t)j * G + o];
+                s->real_goal[o] = a;
+            }
+            if (pos == step)
+                for (int o = 0; o < G; ++o) s->real_goal[o] += w->goal_init[(size_t)b * G + o];
+        }
+    }
+}
+
+static int leak_check(const OrcLeakWeights* w, const OrcDisWeights* d, int B, int L) {
+    if (w->G != d->F || B > w->B_init || w->step_size < 1 || L < 2) return -2;
+    for (int k = 0; k < d->n_filters; ++k) if (d->f[k] > L) return -1;
+    return 0;
+}
+
+/* ROLLOUT.rollout_mc_search_leakgan for every (rollout i, t) pair of get_reward_leakgan's loops
+ * (utils/rollout.py:57-126, 172-175; given_num = t*step_size + 1), one row per (i, t, b):
+ *   for pos in 0..L-1:
+ *     token  = sentences[b,pos] if pos < given_num, else the canonical draw from exp(out) of the step before
+ *              (rollout.py:76-77, 101-102);
+ *     feature = dis.get_feature(tokens 0..pos, zero-padded to L)                  (rollout.py:75-81, 105-108)
+ *     LeakGAN_G.forward(pos, token, ..., feature, real_goal, train=True)          (LeakGAN_G.py:52-102):
+ *        manager LSTM on the feature, cur_goal = normalize(mana2goal(h_m)), rg = normalize(goal2goal(real_goal)),
+ *        worker LSTM on the token's embedding, out = temperature * (work2goal(h_w).view(V,K) @ rg),
+ *        temperature 1.5 for pos <= 1 else 1.0 (train=True), log_softmax;
+ *     goal_array[pos] = cur_goal; if pos > 0 and pos % step_size == 0: real_goal = sum(goal_array[pos-3..pos])
+ *        (+ goal_init[b] when pos == step_size)                                   (rollout.py:89-93, 117-121)
+ * The forward after the last token is skipped (its outputs are never read).
+ * uniforms [R,T,L,B] (draw for position pos at [i,t,pos,b]); completions [R,T,B,L];
+ * forced [R,T,B,L] or NULL = replay mode: the drawn token is written, the forced one is fed on (to the worker and to
+ * the feature extractor). */
+int orc_leak_rollout(const OrcLeakWeights* w, const OrcDisWeights* d, const int64_t* sentences, int B, int L, int R,
+                     int i_lo, int i_hi, const float* uniforms, const int64_t* forced, int64_t* completions) {
+    const int T = L / w->step_size;
+    int rc = leak_check(w, d, B, L);
+    if (rc) return rc;
+    LeakCtx c; leak_ctx_init(&c, w, d);
+    const long n_items = (long)(i_hi - i_lo) * T * B;
+#pragma omp parallel
+    {
+        LeakScratch s; leak_scratch_init(&s, &c, L);
+#pragma omp for schedule(dynamic, 1)
+        for (long it = 0; it < n_items; ++it) {
+            const int b = (int)(it % B);
+            const int t = (int)((it / B) % T);
+            const int i = (int)(it / ((long)B * T)) + i_lo;
+            const size_t row = ((size_t)i * T + t) * B + b;
+            leak_row(&c, &s, sentences + (size_t)b * L, b, L, t * w->step_size + 1,
+                     uniforms + ((size_t)i * T + t) * L * B + b, (size_t)B, forced ? forced + row * L : NULL,
+                     completions + row * L, -1, NULL);
+        }
+        leak_scratch_free(&s);
+    }
+    leak_ctx_free(&c);
+    return 0;
+}
+
+/* The generator's outputs (temperature * work2goal(h_w).view(V,K) @ rg, before log_softmax) after feeding
+ * tokens[0..pos] of one row whose goal_init row is b: what the draw of position pos+1 is taken from.  For the
+ * parity tests' CDF-tie check. */
+int orc_leak_logits_at(const OrcLeakWeights* w, const OrcDisWeights* d, const int64_t* tokens, int b, int L, int pos,
+                       float* logits_out) {
+    int rc = leak_check(w, d, b + 1, L);
+    if (rc || pos < 0 || pos >= L - 1) return rc ? rc : -2;
+    LeakCtx c; leak_ctx_init(&c, w, d);
+    LeakScratch s; leak_scratch_init(&s, &c, L);
+    leak_row(&c, &s, tokens, b, L, L, NULL, 0, NULL, NULL, pos, logits_out);
+    leak_scratch_free(&s);
+    leak_ctx_free(&c);
+    return 0;
+}
+
+/* ROLLOUT.get_reward_leakgan (utils/rollout.py:156-184) end to end: completions [R,T,B,L] (T = L // step_size),
+ * raw [R*T, B] (row i*T + t = softmax(dis(samples))[:, col], D's dropout from dropout_uniforms [R*T*B, F] or NULL),
+ * out [B,T] = mean over the last axis of raw viewed as [B,T,R] (rollout.py:182-183: a reinterpretation of the flat
+ * buffer, like get_reward's) or NULL. */
+int orc_get_reward_leakgan(const OrcLeakWeights* g, const OrcDisWeights* d, const int64_t* sentences, int B, int L,
+                           int R, int i_lo, int i_hi, int col, const float* uniforms, float dropout_p,
+                           const float* dropout_uniforms, int64_t* completions, float* raw, float* out) {
+    const int T = L / g->step_size;
+    int rc = orc_leak_rollout(g, d, sentences, B, L, R, i_lo, i_hi, uniforms, NULL, completions);
+    if (rc) return rc;
+    const size_t row0 = (size_t)i_lo * T * B;
+    const int n = (i_hi - i_lo) * T * B;
+    rc = orc_dis_forward(d, completions + row0 * L, n, L, col, dropout_p,
+                         dropout_uniforms ? dropout_uniforms + row0 * d->F : NULL, raw + row0, NULL, NULL);
+    if (rc) return rc;
+    if (out) orc_reward_reduce(raw, B, T, R, out);
     return 0;
 }

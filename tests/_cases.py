@@ -68,7 +68,6 @@ def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, t
     exp(logit - max) whose logits carry ~1e-6 relative error (H-term fp32 dot products of magnitude up to ~15 with
     N(0,1) weights), far above the 1.2e-7 of a single fp32 rounding, far below the 2e-5 accepted in round 1.  Every
     disagreement is inspected (up to max_check = 1000 per call; more than that fails min_agree on any case here)."""
-    import os
     from oracle import oracle
     R, L, B, _ = ref.shape
     m = sampled_mask(R, L, B)
@@ -77,15 +76,28 @@ def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, t
     assert agree >= min_agree, "step-wise token agreement %.6f" % agree
     assert np.array_equal(got_replay[~m], ref[~m]), "prefix tokens must be copied verbatim"
     idx = np.argwhere(diff)
+
+    def logits_of(i, gi, b, t):
+        row = ref[i, gi, b].astype(np.int64)
+        r = oracle.gen_teacher_forced(gen_oracle, row[None, :], want_logits=True)
+        return r["logits"][0, t - 1]
+
+    _check_ties(idx, got_replay, ref, uniforms, logits_of, tie_tol, max_check, int(m.sum()), what)
+    return agree
+
+
+def _check_ties(idx, got, ref, uniforms, logits_of, tie_tol, max_check, draws, what):
+    """Every disagreement got != ref at idx = (i, j, b, t) must be a CDF tie: the two tokens are neighbours in CDF
+    order and every boundary between them lies within tie_tol of the draw's uniform u[i, j, t, b].  logits_of(i, j,
+    b, t) returns the oracle's logits the draw was taken from.  Records the session's statistics in TIE_STATS."""
+    import os
     assert len(idx) <= max_check, "%d disagreements: more than the %d this check inspects" % (len(idx), max_check)
     worst = 0.0
     for (i, gi, b, t) in idx:
-        row = ref[i, gi, b].astype(np.int64)
-        r = oracle.gen_teacher_forced(gen_oracle, row[None, :], want_logits=True)
-        lg = r["logits"][0, t - 1].astype(np.float64)
+        lg = logits_of(i, gi, b, t).astype(np.float64)
         w = np.exp(lg - lg.max())
         cdf = np.cumsum(w) / w.sum()
-        a, c = int(got_replay[i, gi, b, t]), int(ref[i, gi, b, t])
+        a, c = int(got[i, gi, b, t]), int(ref[i, gi, b, t])
         u = float(uniforms[i, gi, t, b])
         lo, hi = min(a, c), max(a, c)
         # every boundary between the two tokens must sit within tie_tol of u
@@ -94,9 +106,47 @@ def check_token_parity(got_replay, ref, uniforms, gen_oracle, min_agree=0.999, t
         worst = max(worst, gap)
     key = what or os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
     st = TIE_STATS.setdefault(key, {"draws": 0, "disagreements": 0, "max_tie_gap": 0.0})
-    st["draws"] += int(m.sum())
+    st["draws"] += draws
     st["disagreements"] += int(len(idx))
     st["max_tie_gap"] = max(st["max_tie_gap"], worst)
+
+
+# ------------------------------------------------------------------ LeakGAN rollout
+def leak_inputs(c):
+    """(LeakGAN_G state_dict, LeakGAN_D state_dict, sentences [B,L], uniforms [R,T,L,B], dropout uniforms or None)
+    of a leak_reward golden (tools/make_goldens_leak.py)."""
+    V, E, H, K, G, L, B, R, step = [int(c[k]) for k in ("V", "E", "H", "K", "G", "L", "B", "R", "step")]
+    gsd = synth.leak_state(V, E, H, K, G, B, seed=int(c["gseed"]), std=float(c["gstd"]))
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=int(c["dseed"]))
+    T = L // step
+    sent = synth.tokens(int(c["sseed"]), (B, L), V)
+    u = synth.uniform01(int(c["useed"]), (R, T, L, B))
+    du = synth.uniform01(int(c["useed"]) + 7, (R * T, B, G)) if int(c["dropout"]) else None
+    return gsd, dsd, sent, u, du
+
+
+def leak_sampled_mask(R, T, B, L, step):
+    """True where completions[i, t, b, pos] is a sampled position (pos >= given_num = t*step + 1)."""
+    g = (np.arange(T) * step + 1)[:, None]
+    pos = np.arange(L)[None, :]
+    return np.broadcast_to((pos >= g)[None, :, None, :], (R, T, B, L))
+
+
+def check_leak_token_parity(got_replay, ref, uniforms, leak_oracle, dis_oracle, min_agree=0.999, tie_tol=1e-6,
+                            max_check=1000, what=None):
+    """check_token_parity for rollout_mc_search_leakgan's completions [R,T,B,L] (uniforms [R,T,L,B])."""
+    from oracle import oracle
+    R, T, B, L = ref.shape
+    m = leak_sampled_mask(R, T, B, L, leak_oracle.step_size)
+    diff = (got_replay != ref) & m
+    agree = 1.0 - diff.sum() / max(1, m.sum())
+    assert agree >= min_agree, "step-wise token agreement %.6f" % agree
+    assert np.array_equal(got_replay[~m], ref[~m]), "prefix tokens must be copied verbatim"
+
+    def logits_of(i, t, b, pos):
+        return oracle.leak_logits_at(leak_oracle, dis_oracle, ref[i, t, b].astype(np.int64), b, pos - 1)
+
+    _check_ties(np.argwhere(diff), got_replay, ref, uniforms, logits_of, tie_tol, max_check, int(m.sum()), what)
     return agree
 
 

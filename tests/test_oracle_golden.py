@@ -126,3 +126,34 @@ def test_pg_loss_grads_match_reference(name):
     assert loss == pytest.approx(float(c["loss"]), rel=2e-6)
     _cases.assert_grads_close(grads, {k: c["grad." + k] for k in _cases.PG_KEYS}, rel=2e-5, what=name)
     assert not grads["embeddings.weight"][int(c["padding_idx"])].any()
+
+
+@pytest.mark.parametrize("name", _cases.names("leak_reward"))
+def test_leak_reward_matches_reference(name):
+    """oracle.leak_rollout / get_reward_leakgan against the reference's own rollout_mc_search_leakgan /
+    get_reward_leakgan (utils/rollout.py:57-126,156-184) driving LeakGAN_G.forward and LeakGAN_D
+    (tools/make_goldens_leak.py): step-wise token parity with CDF-tie check, raw rows and [B,T] rewards."""
+    c = _cases.load(name)
+    gsd, dsd, sent, u, du = _cases.leak_inputs(c)
+    gen, dis = oracle.Leak(gsd, int(c["step"])), oracle.Dis(dsd)
+    R, L, B = int(c["R"]), int(c["L"]), int(c["B"])
+    T = L // int(c["step"])
+    ref = c["completions"].astype(np.int64)
+    assert ref.shape == (R, T, B, L)
+    replay = oracle.leak_rollout(gen, dis, sent, R, u, forced=ref)
+    _cases.check_leak_token_parity(replay, ref, u, gen, dis)
+    r = oracle.get_reward_leakgan(gen, dis, sent, R, u, col=int(c["current_k"]) + 1, dropout_p=float(c["dropout_p"]),
+                                  dropout_uniforms=du)
+    same = (r["completions"] == ref).all(-1).reshape(R * T, B)
+    assert same.mean() >= 0.98, same.mean()
+    np.testing.assert_allclose(r["raw"][same], c["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, T, R).all(-1)
+    np.testing.assert_allclose(r["reward"][ok], c["reward"][ok], atol=1e-4, rtol=0)
+    # shards of the rollout index on their own equal the full call
+    if R > 1:
+        part = oracle.get_reward_leakgan(gen, dis, sent, R, u, col=int(c["current_k"]) + 1,
+                                         dropout_p=float(c["dropout_p"]), dropout_uniforms=du, i_lo=1, i_hi=R,
+                                         reduce=False)
+        assert np.array_equal(part["completions"][1:], r["completions"][1:])
+        assert np.array_equal(part["raw"][T:], r["raw"][T:]) and not part["raw"][:T].any()
+    np.testing.assert_allclose(oracle.reward_reduce(c["raw"], B, T, R), c["reward"], atol=1e-6, rtol=0)

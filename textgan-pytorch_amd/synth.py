@@ -60,6 +60,23 @@ def gen_state(V, E, H, seed=0, std=1.0):
     return {k: normal_like(seed * 1000 + 17 * i + 1, s, std) for i, (k, s) in enumerate(shapes)}
 
 
+def leak_state(V, E, H, K=16, G=1720, B_init=64, seed=0, std=0.1):
+    """LeakGAN_G state_dict as numpy arrays (models/LeakGAN_G.py:40-48 keys): worker / manager LSTMs, work2goal
+    [V*K, H], mana2goal [G, H], goal2goal [K, G] (no bias), goal_init [B_init, G] ~ U[0,1) (torch.rand, :48).
+    G = goal_out_size = the discriminator's feature width, K = goal_size."""
+    shapes = [("embeddings.weight", (V, E)),
+              ("worker.weight_ih_l0", (4 * H, E)), ("worker.weight_hh_l0", (4 * H, H)),
+              ("worker.bias_ih_l0", (4 * H,)), ("worker.bias_hh_l0", (4 * H,)),
+              ("manager.weight_ih_l0", (4 * H, G)), ("manager.weight_hh_l0", (4 * H, H)),
+              ("manager.bias_ih_l0", (4 * H,)), ("manager.bias_hh_l0", (4 * H,)),
+              ("work2goal.weight", (V * K, H)), ("work2goal.bias", (V * K,)),
+              ("mana2goal.weight", (G, H)), ("mana2goal.bias", (G,)),
+              ("goal2goal.weight", (K, G))]
+    sd = {k: normal_like(seed * 1000 + 701 + 13 * i, s, std) for i, (k, s) in enumerate(shapes)}
+    sd["goal_init"] = uniform01(seed * 1000 + 799, (B_init, G))
+    return sd
+
+
 SEQGAN_D_FILTERS = ([1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 15, 20],
                     [100, 200, 200, 200, 200, 100, 100, 100, 100, 100, 160, 160])  # models/SeqGAN_D.py:12-13
 SENTIGAN_D_FILTERS = ([2, 3, 4, 5], [200, 200, 200, 200])  # models/SentiGAN_D.py:14-15
