@@ -298,6 +298,55 @@ int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * LeakGAN Monte-Carlo completions.
+ * Replaces ROLLOUT.rollout_mc_search_leakgan (utils/rollout.py:57-126) for every (rollout index i, given_num) pair
+ * of ROLLOUT.get_reward_leakgan's loops (utils/rollout.py:172-175) in one call: per position the discriminator's
+ * get_feature over the tokens so far (models/discriminator.py:51-64, zero padded as rollout.py:75-76 / 105 have it),
+ * LeakGAN_G.forward(idx, token, ..., feature, real_goal, train=True) (models/LeakGAN_G.py:52-102: manager LSTM,
+ * worker LSTM, work2goal(h_w).view(V,K) @ normalize(goal2goal(real_goal)), temperature, log_softmax), the goal
+ * bookkeeping (rollout.py:89-93, 117-121) and torch.multinomial(exp(out), 1) as the canonical inverse-CDF draw.
+ * LeakGAN_G parameters: models/LeakGAN_G.py:40-48 (state_dict keys embeddings.weight, worker.*_l0, manager.*_l0,
+ * work2goal.*, mana2goal.*, goal2goal.weight, goal_init); G = goal_out_size must equal the scorer's F.
+ *   sentences   [B,L]       int64
+ *   given_nums  [T] (HOST)  given_num of column t (get_reward_leakgan: t*step_size + 1; one value for a single
+ *                           rollout_mc_search_leakgan call), each in [1, L]; T <= 64
+ *   uniforms    [R,T,L,B]   fp32 in [0,1): the draw for rollout i, column t, position pos, sentence b is
+ *                           uniforms[((i*T + t)*L + pos)*B + b] (pos >= given_nums[t] used)
+ *   forced      [R,T,B,L]   int64 or NULL: replay mode (the drawn token is written, the forced one is fed on, to the
+ *                           worker and to the feature extractor)
+ *   completions [R,T,B,L]   int64; only i in [i_lo, i_hi) is written
+ *   workspace   tg_leak_rollout_workspace_bytes(g, d, B, L, T, i_hi - i_lo) bytes
+ * Supported: hidden size a multiple of 32 up to 128, goal_size <= 64, V <= 32768, B <= goal_init's rows; the scorer
+ * as in tg_dis_score (d->precision selects its arithmetic; the generator side is fp32 MFMA / fp64). */
+typedef struct TgLeakWeights {
+    const float* emb;       /* embeddings.weight     [V,E]    */
+    const float* w_wih;     /* worker.weight_ih_l0   [4H,E]   */
+    const float* w_whh;     /* worker.weight_hh_l0   [4H,H]   */
+    const float* w_bih;     /* worker.bias_ih_l0     [4H]     */
+    const float* w_bhh;     /* worker.bias_hh_l0     [4H]     */
+    const float* m_wih;     /* manager.weight_ih_l0  [4H,G]   */
+    const float* m_whh;     /* manager.weight_hh_l0  [4H,H]   */
+    const float* m_bih;     /* manager.bias_ih_l0    [4H]     */
+    const float* m_bhh;     /* manager.bias_hh_l0    [4H]     */
+    const float* w2g_w;     /* work2goal.weight      [V*K,H]  */
+    const float* w2g_b;     /* work2goal.bias        [V*K]    */
+    const float* m2g_w;     /* mana2goal.weight      [G,H]    */
+    const float* m2g_b;     /* mana2goal.bias        [G]      */
+    const float* g2g_w;     /* goal2goal.weight      [K,G]    */
+    const float* goal_init; /* goal_init             [B_init,G] */
+    int32_t V, E, H, G, K;  /* K = goal_size, G = goal_out_size */
+    int32_t step_size;      /* LeakGAN_G.step_size (models/LeakGAN_G.py:36) */
+    int32_t B_init;         /* rows of goal_init (cfg.batch_size at construction, models/LeakGAN_G.py:48) */
+    float temperature;      /* LeakGAN_G.temperature (1.5, :38): applied at positions 0 and 1 */
+} TgLeakWeights;
+size_t tg_leak_rollout_workspace_bytes(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, int T,
+                                       int n_i /* rollout indices of the call: i_hi - i_lo */);
+int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, const int64_t* sentences,
+                    int B, int L, int R, const int32_t* given_nums, int T, int i_lo, int i_hi,
+                    const float* uniforms, const int64_t* forced, int64_t* completions,
+                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Reward reshape + mean.
  * Replaces torch.mean(rewards.view(B, L, R), dim=-1) (utils/rollout.py:153):
  * a reinterpretation of the flat [R*L, B] buffer, not a permute:
@@ -331,6 +380,9 @@ int tg_allgather_rows(float* raw, size_t rows_per_rank, size_t B, void* rccl_com
 #define TG_KERNEL_GENW_CELL 9     /* k_genw_gemm<cell>: gates GEMM + state update  */
 #define TG_KERNEL_GENW_PROJ 10    /* k_genw_gemm<proj>: vocabulary GEMM + records  */
 #define TG_KERNEL_GENW_DRAW 11    /* k_genw_draw                                   */
+#define TG_KERNEL_LEAK_DRAW 12    /* k_leak_draw                                   */
+#define TG_KERNEL_LEAK_CELLS 13   /* k_leak_cells                                  */
+#define TG_KERNEL_LEAK_PROJ 14    /* k_leak_proj                                   */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

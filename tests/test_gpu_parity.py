@@ -606,6 +606,81 @@ def test_mali_reward(name, precision):
     assert torch.isfinite(ev).all() and abs(float(ev[:, 0].sum())) < 1e-6
 
 
+# ------------------------------------------------------------------ LeakGAN rollout
+def _leak_models(c):
+    gsd, dsd, sent, u, du = _cases.leak_inputs(c)
+    V, E, H, K, L, B, step = [int(c[k]) for k in ("V", "E", "H", "K", "L", "B", "step")]
+    gen = tg.modules.load_numpy_state(tg.modules.LeakGAN_G(E, H, V, L, goal_size=K, step_size=step, batch_size=B), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V, dropout=0.2), dsd, DEV)
+    return gen, dis, oracle.Leak(gsd, step), oracle.Dis(dsd), sent, u, du
+
+
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
+@pytest.mark.parametrize("name", _cases.names("leak_reward"))
+def test_leak_rollout_and_reward(name, precision):
+    """tg_leak_rollout / ROLLOUT.get_reward_leakgan against the reference's rollout_mc_search_leakgan /
+    get_reward_leakgan goldens (tools/make_goldens_leak.py) and the oracle; `precision` is the scorer's arithmetic
+    (the manager's input and the final rewards), the generator side is fp32 / fp64."""
+    c = _cases.load(name)
+    gen, dis, og, od, sent, u, du = _leak_models(c)
+    R, L, B, step = int(c["R"]), int(c["L"]), int(c["B"]), int(c["step"])
+    T = L // step
+    given = [t * step + 1 for t in range(T)]
+    ref = c["completions"].astype(np.int64)
+    replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(ref), dis_precision=precision)
+    _cases.check_leak_token_parity(replay.cpu().numpy(), ref, u, og, od)
+    free = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), dis_precision=precision)
+    assert (free.cpu().numpy() == ref).all(-1).mean() >= 0.97
+    if R > 1:  # a shard of the rollout index on its own
+        part = torch.full_like(free, -1)
+        tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), i_lo=1, i_hi=R, out=part, dis_precision=precision)
+        assert torch.equal(part[1:], free[1:]) and bool((part[0] == -1).all())
+    # the drop-in surface
+    if int(c["dropout"]):
+        dis.train()
+    else:
+        dis.eval()
+    ro = tg.ROLLOUT(gen, True)
+    ro.dis_precision = precision
+    assert ro.step_size == step and ro.goal_out_size == od.F
+    rew, raw, comp = ro.get_reward_leakgan(_t(sent), R, dis, int(c["current_k"]), uniforms=_t(u),
+                                           dropout_uniforms=None if du is None else _t(du), return_parts=True)
+    assert rew.is_cuda and tuple(rew.shape) == (B, T) and torch.equal(comp, free)
+    comp, raw, rew = comp.cpu().numpy(), raw.cpu().numpy(), rew.cpu().numpy()
+    same = (comp == ref).all(-1).reshape(R * T, B)
+    np.testing.assert_allclose(raw[same], c["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, T, R).all(-1)
+    assert ok.mean() >= 0.9
+    np.testing.assert_allclose(rew[ok], c["reward"][ok], atol=1e-4, rtol=0)
+    one = ro.rollout_mc_search_leakgan(_t(sent), dis, given[1], uniforms=_t(u[:1, 1:2]))
+    assert torch.equal(one, free[0, 1])
+
+
+def test_leak_reward_c1_shape_full_vs_oracle():
+    """run_leakgan.py's configuration at full size (V5000 L20 E=H=32 goal 16 step 4, B64, rollout_num 4: 1 280
+    completions, 14 080 draws) against the oracle: step-wise token parity with CDF-tie check, rewards of agreeing rows."""
+    V, E, H, K, L, B, R, step = 5000, 32, 32, 16, 20, 64, 4, 4
+    gsd = synth.leak_state(V, E, H, K, 1720, B, seed=7, std=0.2)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=7)
+    gen = tg.modules.load_numpy_state(tg.modules.LeakGAN_G(E, H, V, L, goal_size=K, step_size=step, batch_size=B), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V, dropout=0.2), dsd, DEV).eval()
+    og, od = oracle.Leak(gsd, step), oracle.Dis(dsd)
+    T = L // step
+    sent, u = synth.tokens(71, (B, L), V), synth.uniform01(72, (R, T, L, B))
+    o = oracle.get_reward_leakgan(og, od, sent, R, u)
+    given = [t * step + 1 for t in range(T)]
+    replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(o["completions"]))
+    _cases.check_leak_token_parity(replay.cpu().numpy(), o["completions"], u, og, od)
+    rew, raw, comp = tg.ROLLOUT(gen).get_reward_leakgan(_t(sent), R, dis, 0, uniforms=_t(u), return_parts=True)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * T, B)
+    assert same.mean() >= 0.97
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, T, R).all(-1)
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
+    for t in range(T):  # the first given_num tokens are the sentence's
+        assert torch.equal(comp[:, t, :, :given[t]], _t(sent)[:, :given[t]].expand(R, B, given[t]))
+
+
 def test_errors_and_cpu_inputs():
     gen = tg.modules.synthetic_generator(100, 32, 32, 20, device=DEV)
     with pytest.raises(RuntimeError):

@@ -19,11 +19,13 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_dis_workspace_bytes",
            "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
            "tg_gen_nll_workspace_bytes", "tg_gen_nll", "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
+           "tg_leak_rollout_workspace_bytes", "tg_leak_rollout",
            "tg_reward_reduce", "tg_allgather_rows",
            "tg_profile_enable", "tg_profile_read"]
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
-           "dis_prefix": 6, "pg_backward": 7, "pg_forward": 8, "genw_cell": 9, "genw_proj": 10, "genw_draw": 11}
+           "dis_prefix": 6, "pg_backward": 7, "pg_forward": 8, "genw_cell": 9, "genw_proj": 10, "genw_draw": 11,
+           "leak_draw": 12, "leak_cells": 13, "leak_proj": 14}
 
 
 class GenW(C.Structure):
@@ -34,6 +36,13 @@ class GenW(C.Structure):
 class GenGrads(C.Structure):
     """TgGenGrads: gradient buffers, same order and shapes as the GenW pointers."""
     _fields_ = [(k, C.c_void_p) for k in ("emb", "w_ih", "w_hh", "b_ih", "b_hh", "w_out", "b_out")]
+
+
+class LeakW(C.Structure):
+    """TgLeakWeights: LeakGAN_G parameters (models/LeakGAN_G.py:40-48)."""
+    _fields_ = [(k, C.c_void_p) for k in ("emb", "w_wih", "w_whh", "w_bih", "w_bhh", "m_wih", "m_whh", "m_bih", "m_bhh",
+                                          "w2g_w", "w2g_b", "m2g_w", "m2g_b", "g2g_w", "goal_init")] + \
+               [(k, C.c_int32) for k in ("V", "E", "H", "G", "K", "step_size", "B_init")] + [("temperature", C.c_float)]
 
 
 class DisW(C.Structure):
@@ -96,6 +105,12 @@ def lib():
         l.tg_gen_nll.restype = C.c_int
         l.tg_gen_pg_forward.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4
         l.tg_gen_pg_forward.restype = C.c_int
+        l.tg_leak_rollout_workspace_bytes.restype = C.c_size_t
+        l.tg_leak_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.tg_leak_rollout.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                      C.c_void_p]
+        l.tg_leak_rollout.restype = C.c_int
         l.tg_allgather_rows.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
         l.tg_allgather_rows.restype = C.c_int
         l.tg_profile_enable.argtypes = [C.c_int]
@@ -167,6 +182,32 @@ def gen_weights(gen, precision=None):
         raise RuntimeError("textgan_hip: generator shape V=%d E=%d H=%d is not supported by the compiled kernels "
                            "(every entry point: H in {32,64,128,256,512}, E a multiple of 32 up to 512; rollout / sample "
                            "/ NLL in split_f16: E, H multiples of 32 up to 1024)" % (V, E, H))
+    return w, keep
+
+
+def leak_weights(gen):
+    """Pack the live parameters of a LeakGAN_G-shaped module (models/LeakGAN_G.py:40-48): embeddings, worker and
+    manager LSTMs, work2goal, mana2goal, goal2goal, goal_init, with step_size / temperature from the module."""
+    names = (("embeddings.weight", gen.embeddings.weight),
+             ("worker.weight_ih_l0", gen.worker.weight_ih_l0), ("worker.weight_hh_l0", gen.worker.weight_hh_l0),
+             ("worker.bias_ih_l0", gen.worker.bias_ih_l0), ("worker.bias_hh_l0", gen.worker.bias_hh_l0),
+             ("manager.weight_ih_l0", gen.manager.weight_ih_l0), ("manager.weight_hh_l0", gen.manager.weight_hh_l0),
+             ("manager.bias_ih_l0", gen.manager.bias_ih_l0), ("manager.bias_hh_l0", gen.manager.bias_hh_l0),
+             ("work2goal.weight", gen.work2goal.weight), ("work2goal.bias", gen.work2goal.bias),
+             ("mana2goal.weight", gen.mana2goal.weight), ("mana2goal.bias", gen.mana2goal.bias),
+             ("goal2goal.weight", gen.goal2goal.weight), ("goal_init", gen.goal_init))
+    keep, ptrs = [], []
+    for name, p in names:
+        d, ptr = _param(p, name)
+        keep.append(d)
+        ptrs.append(ptr)
+    V, E = keep[0].shape
+    H = keep[2].shape[1]
+    K, G = keep[13].shape
+    if (keep[1].shape != (4 * H, E) or keep[5].shape != (4 * H, G) or keep[9].shape != (V * K, H)
+            or keep[11].shape != (G, H) or keep[14].shape[1] != G):
+        raise RuntimeError("textgan_hip: LeakGAN generator parameter shapes are inconsistent")
+    w = LeakW(*ptrs, V, E, H, G, K, int(gen.step_size), int(keep[14].shape[0]), float(getattr(gen, "temperature", 1.5)))
     return w, keep
 
 

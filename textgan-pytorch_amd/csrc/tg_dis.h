@@ -1,0 +1,12 @@
+// Internal entry of the scorer (tg_dis.hip) used by the LeakGAN rollout's position loop (tg_leak.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/textgan_hip.h"
+
+// CNNDiscriminator.get_feature over [N,L] sequences -> feature_out [N,F]; workspace of tg_dis_workspace_bytes(w,N,L).
+// reuse = the workspace already holds the prepared (scaled, split) weights a previous call wrote for the same w and N.
+int tg_dis_features(const TgDisWeights* w, const int64_t* seqs, int N, int L, float* feature_out, void* workspace,
+                    size_t workspace_bytes, bool reuse, hipStream_t stream);

@@ -1249,14 +1249,16 @@ size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
 // of all conv banks, the two power-of-two scales, and the (hi, lo) halves of the conv weights.
-int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, hipStream_t stream) {
+// reuse: the workspace still holds the scales and halves an earlier call wrote for the SAME weights and N (the
+// position loop of tg_leak_rollout): only the offsets are recomputed and the pooled |max| slot is cleared.
+int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, hipStream_t stream, bool reuse) {
     unsigned* absmax = (unsigned*)scal;          // [0] conv weights, [1] embedding table
     float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e), -} x 2 (conv, highway)
-    if (hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
+    if (hipMemsetAsync(reuse ? absmax + 3 : absmax, 0, reuse ? 4 : 16, stream) != hipSuccess) {
         tg_set_error("hipMemsetAsync failed");
         return TG_ERR_LAUNCH;
     }
-    tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+    if (!reuse) tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
     SplitArgs sa = {};
     const MergePlan pl = plan_merge(w);
     int off = 0, maxcount = 0, maxelems = 0, foff = 0;
@@ -1287,17 +1289,19 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     off = (off + 127) & ~127;  // the row tables behind the fragments, 256-B aligned
     sa.mmeta = reinterpret_cast<MergedMeta*>(w16 + off);
     ca.mmeta = sa.mmeta;
-    hipLaunchKernelGGL(k_absmax_banks, dim3(tg_min_host((maxelems + 255) / 256, 64), w->n_filters), dim3(256), 0, stream,
-                       sa, absmax);
-    const size_t ne = (size_t)w->V * kEd;
-    hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 256)), dim3(256), 0, stream, w->emb, ne,
-                       absmax + 1);
-    hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
     sa.w16 = w16;
     sa.scales = scales;
-    hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters + pl.n_merged),
-                       dim3(256), 0, stream, sa);
-    tg_prof_end(stream);
+    if (!reuse) {
+        hipLaunchKernelGGL(k_absmax_banks, dim3(tg_min_host((maxelems + 255) / 256, 64), w->n_filters), dim3(256), 0,
+                           stream, sa, absmax);
+        const size_t ne = (size_t)w->V * kEd;
+        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 256)), dim3(256), 0, stream, w->emb, ne,
+                           absmax + 1);
+        hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
+        hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters + pl.n_merged),
+                           dim3(256), 0, stream, sa);
+        tg_prof_end(stream);
+    }
     ca.w16 = w16;
     ca.scales = scales;
     ca.pooled_absmax = absmax + 3;  // read by the highway's scale (score_impl)
@@ -1330,7 +1334,7 @@ int launch_highway_split(HsArgs& hs, hipStream_t stream) {
 // sentences != nullptr: seqs is [R,L,B,L] rollout completions (N = R*L*B), prefix reuse.
 int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const int64_t* sentences, int B, int col,
                float dropout_p, const float* dropout_uniforms, float* reward_out, float* logits_out,
-               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream) {
+               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream, bool reuse = false) {
     if (N < 0 || L < 1 || !seqs) {
         tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
@@ -1365,7 +1369,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     rc = prepare_conv(ca, w, sentences ? B : N, L, &sm);
     if (rc) return rc;
     if (w->precision == TG_DIS_SPLIT_F16) {
-        rc = prepare_split(ca, w, w16, scal, stream);
+        rc = prepare_split(ca, w, w16, scal, stream, reuse);
         if (rc) return rc;
     } else if (w->precision != TG_DIS_FP32) {
         tg_set_error("tg_dis_score: unknown precision %d", w->precision);
@@ -1428,11 +1432,14 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         float* scales = (float*)((char*)scal + 16) + 4;
         const size_t nw = (size_t)w->F * w->F;
         tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
-        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 512)), dim3(256), 0, stream, w->hw_w, nw,
-                           absmax);
+        if (!reuse)
+            hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 512)), dim3(256), 0, stream, w->hw_w,
+                               nw, absmax);
+        // the pooled features' |max| is this call's own (the conv epilogue left it): the scales are always rebuilt
         hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
-        hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((nw / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
-                           w->hw_w, nw, hw16, hw16 + nw, scales);
+        if (!reuse)
+            hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((nw / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
+                               w->hw_w, nw, hw16, hw16 + nw, scales);
         tg_prof_end(stream);
         HsArgs hs = {};
         hs.h = ha;
@@ -1603,6 +1610,14 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
                             void* workspace, size_t workspace_bytes, void* stream) {
     return score_impl(w, seqs, N, L, nullptr, 0, col, dropout_p, dropout_uniforms, reward_out, logits_out,
                       feature_out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// get_feature for the LeakGAN rollout's position loop (tg_leak.hip): tg_dis_score restricted to feature_out, with
+// `reuse` = the workspace already holds this call's prepared weights (same w, same N as the call that wrote them).
+int tg_dis_features(const TgDisWeights* w, const int64_t* seqs, int N, int L, float* feature_out, void* workspace,
+                    size_t workspace_bytes, bool reuse, hipStream_t stream) {
+    return score_impl(w, seqs, N, L, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, feature_out, workspace,
+                      workspace_bytes, stream, reuse);
 }
 
 extern "C" size_t tg_dis_score_rollout_workspace_bytes(const TgDisWeights* w, int B, int L, int R) {

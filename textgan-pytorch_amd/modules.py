@@ -4,6 +4,7 @@ where the reference tree is absent.  A real training run keeps using the
 reference's own classes -- the HIP path reads any module with these attributes.
 
   LSTMGenerator     models/generator.py:18-38   (SeqGAN_G / MaliGAN_G / SentiGAN_G / Oracle: :16-19 of each)
+  LeakGAN_G         models/LeakGAN_G.py:23-50
   CNNDiscriminator  models/discriminator.py:20-38
   SeqGAN_D          models/SeqGAN_D.py:12-19    (MaliGAN_D identical)
   SentiGAN_D        models/SentiGAN_D.py:14-28
@@ -30,6 +31,26 @@ class LSTMGenerator(nn.Module):
         p = self.lstm2out.weight
         z = torch.zeros(1, batch_size, self.hidden_dim, device=p.device, dtype=p.dtype)
         return z, z.clone()
+
+
+class LeakGAN_G(nn.Module):
+    """State_dict-compatible shell of models/LeakGAN_G.py:23-50 (parameters and the attributes the rollout reads)."""
+
+    def __init__(self, embedding_dim, hidden_dim, vocab_size, max_seq_len, padding_idx=0, goal_size=16, step_size=4,
+                 gpu=True, goal_out_size=sum(synth.SEQGAN_D_FILTERS[1]), batch_size=64):
+        super().__init__()
+        self.name = "leakgan"
+        self.hidden_dim, self.embedding_dim = hidden_dim, embedding_dim
+        self.max_seq_len, self.vocab_size, self.padding_idx = max_seq_len, vocab_size, padding_idx
+        self.goal_size, self.goal_out_size, self.step_size = goal_size, goal_out_size, step_size
+        self.gpu, self.temperature = gpu, 1.5
+        self.embeddings = nn.Embedding(vocab_size, embedding_dim, padding_idx=padding_idx)
+        self.worker = nn.LSTM(embedding_dim, hidden_dim)
+        self.manager = nn.LSTM(goal_out_size, hidden_dim)
+        self.work2goal = nn.Linear(hidden_dim, vocab_size * goal_size)
+        self.mana2goal = nn.Linear(hidden_dim, goal_out_size)
+        self.goal2goal = nn.Linear(goal_out_size, goal_size, bias=False)
+        self.goal_init = nn.Parameter(torch.rand((batch_size, goal_out_size)))
 
 
 class CNNDiscriminator(nn.Module):
@@ -63,6 +84,11 @@ def load_numpy_state(module, sd, device=None):
 def synthetic_generator(V, E, H, L, seed=0, std=1.0, device="cuda"):
     g = LSTMGenerator(E, H, V, L)
     return load_numpy_state(g, synth.gen_state(V, E, H, seed=seed, std=std), device)
+
+
+def synthetic_leakgan(V, E, H, L, goal_size=16, step_size=4, batch_size=64, seed=0, std=0.1, device="cuda"):
+    g = LeakGAN_G(E, H, V, L, goal_size=goal_size, step_size=step_size, batch_size=batch_size)
+    return load_numpy_state(g, synth.leak_state(V, E, H, goal_size, g.goal_out_size, batch_size, seed=seed, std=std), device)
 
 
 def synthetic_discriminator(kind, V, seed=0, k_label=4, device="cuda"):

@@ -150,6 +150,33 @@ def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_l
 
 
 @_on_device
+def leak_rollout(gen, dis, sentences, R, given_nums, uniforms, forced=None, i_lo=0, i_hi=None, out=None,
+                 dis_weights=None, dis_precision=None):
+    """tg_leak_rollout: every rollout_mc_search_leakgan(sentences, dis, given_num) of get_reward_leakgan's loops
+    (utils/rollout.py:57-126,172-175).  given_nums: the T given_num values (t*step_size + 1 for get_reward_leakgan);
+    uniforms [R,T,L,B]; returns completions [R,T,B,L] int64."""
+    w, keep = _lib.leak_weights(gen)
+    dw, dkeep = dis_weights if dis_weights is not None else _lib.dis_weights(dis, dis_precision)
+    s, _ = _tokens(sentences, "sentences")
+    B, L = s.shape
+    T = len(given_nums)
+    i_hi = R if i_hi is None else i_hi
+    if uniforms.numel() != R * T * L * B:
+        raise RuntimeError("textgan_hip: uniforms must have R*T*L*B = %d elements, got %d"
+                           % (R * T * L * B, uniforms.numel()))
+    comp = out if out is not None else torch.empty(R, T, B, L, dtype=I64, device=s.device)
+    given = (C.c_int32 * T)(*[int(g) for g in given_nums])
+    nbytes = _lib.lib().tg_leak_rollout_workspace_bytes(C.byref(w), C.byref(dw), B, L, T, max(1, i_hi - i_lo))
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=s.device)
+    f = None if forced is None else _tokens(forced, "forced")[0]
+    _lib.check(_lib.lib().tg_leak_rollout(
+        C.byref(w), C.byref(dw), _lib.dev_ptr(s, I64, "sentences"), B, L, R, given, T, i_lo, i_hi,
+        _lib.dev_ptr(uniforms, F32, "uniforms"), _lib.dev_ptr(f, I64, "forced"), _lib.dev_ptr(comp, I64, "completions"),
+        _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return comp
+
+
+@_on_device
 def gen_sample(gen, N, L, start_letter, uniforms, forced=None, precision=None):
     """tg_gen_sample: the step loop of LSTMGenerator.sample (models/generator.py:71-81) for N rows.
     uniforms [L,N]; returns [N,L] int64 on the device."""

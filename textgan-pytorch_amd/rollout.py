@@ -147,6 +147,99 @@ class ROLLOUT:
         return rewards
 
 
+    def get_token_reward(self, sentences, rollout_num, dis, current_k, given_num, uniforms=None):
+        """utils/rollout.py:186-204 (no caller in the reference): mean over rollout_num completions from one
+        given_num of softmax(dis(samples))[:, current_k + 1].  Returns [B] on the input's device."""
+        self._check(sentences)
+        R = int(rollout_num)
+        B, L = sentences.shape
+        if not (1 <= given_num <= L):
+            raise RuntimeError("given_num must be in [1, %d]" % L)
+        with torch.no_grad():
+            u = uniforms if uniforms is not None else self._rand((R, L, L, B), sentences.device)
+            comp = ops.gen_rollout(self.gen, sentences, R, u, g_lo=given_num, g_hi=given_num,
+                                   precision=self.gen_precision)[:, given_num - 1].contiguous()
+            p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
+            r = ops.dis_score(dis, comp.view(R * B, L), col=current_k + 1, dropout_p=p,
+                              precision=self.dis_precision)["reward"].view(R, B)
+            return torch.sum(r, dim=0) / R
+
+    def get_reward_csgan(self, target, rollout_num, csgan_clas):
+        """utils/rollout.py:206-207: an empty stub in the reference as well."""
+        return None
+
+    # ------------------------------------------------------------------ LeakGAN (SURVEY.md 8(f)4)
+    def _check_leak(self):
+        if getattr(self.gen, "name", None) != "leakgan" or self.step_size < 1:
+            raise RuntimeError("textgan_hip ROLLOUT: the LeakGAN rollout needs a LeakGAN_G generator (gen.name == 'leakgan')")
+
+    def rollout_mc_search_leakgan(self, sentences, dis, given_num, uniforms=None):
+        """utils/rollout.py:57-126: keep ``given_num`` tokens, complete the rest with LeakGAN_G.forward fed by
+        dis.get_feature at every position. Returns [B, L] int64.  uniforms: optional [1,1,L,B]."""
+        self._check(sentences)
+        self._check_leak()
+        B, L = sentences.shape
+        if not (1 <= given_num <= L):
+            raise RuntimeError("given_num must be in [1, %d]" % L)
+        with torch.no_grad():
+            u = uniforms if uniforms is not None else self._rand((1, 1, L, B), sentences.device)
+            comp = ops.leak_rollout(self.gen, dis, sentences, 1, [given_num], u, dis_precision=self.dis_precision)
+        return comp[0, 0]
+
+    def get_reward_leakgan(self, sentences, rollout_num, dis, current_k, uniforms=None, dropout_uniforms=None,
+                           return_parts=False):
+        """utils/rollout.py:156-184: rewards [B, L // step_size] of the prefixes of length t*step_size + 1.
+
+        uniforms          optional [R, T, L, B] pre-drawn U[0,1) (index [i, t, position, b]), T = L // step_size; the
+                          GLOBAL tensor when a process group shards the rollout index.
+        dropout_uniforms  optional [R*T, B, F] for the discriminator's live dropout in the final scoring
+                          (dis.get_feature inside the rollout has none, models/discriminator.py:51-64)."""
+        self._check(sentences)
+        self._check_leak()
+        R = int(rollout_num)
+        B, L = sentences.shape
+        T = L // self.step_size
+        if T < 1:
+            raise RuntimeError("textgan_hip ROLLOUT: max_seq_len %d shorter than step_size %d" % (L, self.step_size))
+        given = [t * self.step_size + 1 for t in range(T)]
+        dev = sentences.device
+        plan = tdist.ShardPlan.from_group(R, self.group)
+        Rl = plan.i_hi - plan.i_lo
+        with torch.no_grad():
+            if plan.world > 1 and self.sync_weights:
+                with self._timed("sync_weights"):
+                    tdist.sync_weights(self.gen, dis, self.group)
+            if uniforms is None:
+                u = self._rand((Rl, T, L, B), dev, plan)
+            else:
+                u = uniforms.reshape(R, T, L, B)[plan.i_lo:plan.i_hi].contiguous()
+            raw_local = torch.empty(Rl * T, B, dtype=torch.float32, device=dev)
+            comp = None
+            if Rl > 0:
+                weights = _lib.dis_weights(dis, self.dis_precision)
+                F = weights[0].F
+                with self._timed("leak_rollout"):
+                    comp = ops.leak_rollout(self.gen, dis, sentences, Rl, given, u, dis_weights=weights)
+                p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
+                du, seed = None, None
+                if p > 0 and dropout_uniforms is not None:
+                    du = dropout_uniforms.reshape(R * T * B, F)[plan.i_lo * T * B:plan.i_hi * T * B].contiguous()
+                elif p > 0 and self.dropout_rng == "torch":
+                    du = self._rand((Rl * T * B, F), dev, plan)
+                elif p > 0:
+                    seed = _lib.next_dropout_seed(plan.rank)
+                with self._timed("dis_score"):
+                    ops.dis_score(dis, comp.view(Rl * T * B, L), col=current_k + 1, dropout_p=p, dropout_uniforms=du,
+                                  reward_out=raw_local.view(-1), weights=weights, dropout_seed=seed)
+            with self._timed("exchange"):
+                raw = tdist.gather_rows(raw_local, plan, T, self.group)
+            with self._timed("reduce"):
+                rewards = ops.reward_reduce(raw, B, T, R)   # rewards.view(B, T, R).mean(-1) (rollout.py:182-183)
+        if return_parts:
+            return rewards, raw, comp
+        return rewards
+
+
 class _Timed:
     def __init__(self, timers, name):
         self.timers, self.name = timers, name
