@@ -40,6 +40,10 @@ WORKLOADS = {
 SCALED = "c3r8"                 # the `scaled` sub-record of the default line
 PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md, Peak FP32 (matrix)
 PEAK_F16_MFMA_TFLOPS = 2500.0   # MI355X_MICROARCH.md, Peak BF16/FP16 MFMA, dense
+# what v_mfma_f32_32x32x16_f16 sustains on the whole chip from registers alone with non-zero operands (no LDS, no
+# memory): tools/ubench/mfma_f16_peak.hip, profiles/r02_mfma_f16_sustained.txt -- 1 655 TFLOP/s (the clock settles
+# near 1.6 GHz under that power draw); all-zero operands reach the nominal 2 476.  `peak` stays the nominal figure.
+SUSTAINED_F16_MFMA_TFLOPS = 1655.0
 
 
 def flops_model(V, L, E, H, filt, Ed=64, n_out=2):
@@ -237,6 +241,79 @@ def bench_pg(args, dev):
     print(json.dumps(out))
 
 
+def bench_leak(args, dev):
+    """Side workload leak: ROLLOUT.get_reward_leakgan at run_leakgan.py's configuration (vocab 5000,
+    len 20, emb/hidden 32, goal_size 16, step_size 4, batch 64, rollout_num 4; LeakGAN_D with live dropout): 1 280
+    completions per call, each position of each completion costing one get_feature pass of the scorer."""
+    V, L, E, H, K, step, B, R = 5000, 20, 32, 32, 16, 4, 64, args.leak_rollout_num
+    T = L // step
+    gen = tg.modules.synthetic_leakgan(V, E, H, L, K, step, B, seed=0, std=0.2, device=dev)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=dev)
+    dis.dropout.p = 0.2                       # models/LeakGAN_D.py:16
+    if args.eval_mode:
+        dis.eval()
+    sent = torch.from_numpy(tg.synth.tokens(1, (B, L), V)).to(dev)
+    ro = tg.ROLLOUT(gen, True)
+    ro.dis_precision = args.dis_precision
+    for _ in range(args.warmup):
+        ro.get_reward_leakgan(sent, R, dis, 0)
+    torch.cuda.synchronize()
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        rew = ro.get_reward_leakgan(sent, R, dis, 0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = tg._lib.profile_read()
+    tg._lib.profile_enable(False)
+    assert tuple(rew.shape) == (B, T) and bool(torch.isfinite(rew).all())
+    N = R * T * B
+    conv_f, _, hw_f, _ = flops_model(V, L, E, H, tg.synth.SEQGAN_D_FILTERS)
+    split = (args.dis_precision or tg._lib.default_dis_precision) == "split_f16"
+    # per call: L - 1 feature passes over all N rows + the final scoring; work2goal for the rows whose next token is drawn
+    feat_flops = (conv_f + hw_f) * N * L
+    proj_rows = sum(R * B * (L - 1 - max(t * step, 0)) for t in range(T))   # positions pos >= given - 1, pos <= L - 2
+    proj_flops = 2 * (K * H + K) * V * proj_rows
+    kernels = {k: {"avg_ms": ms / n, "launches": n, "ms_per_call": ms / args.steps} for k, (ms, n) in prof.items() if n}
+    conv_ms = kernels["dis_conv"]["ms_per_call"]
+    ach = conv_f * N * L / (conv_ms * 1e-3) / 1e12
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+    kernels["dis_conv"]["tflops"] = ach
+    kernels["leak_proj"]["tflops"] = proj_flops / (kernels["leak_proj"]["ms_per_call"] * 1e-3) / 1e12
+    kernels["leak_proj"]["peak_tflops"] = PEAK_FP32_MFMA_TFLOPS
+    out = {"metric": "LeakGAN MC rollout completions/sec", "value": N * args.steps / dt, "unit": "completions/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (generator: fp32 MFMA, goal algebra f64; scorer: %s)" % ("split-f16 x3" if split else "f32"),
+           "data": "synthetic",
+           "config": {"workload": "run_leakgan.py shape: vocab %d, len %d, emb/hidden %d, goal_size %d, step_size %d, "
+                                  "batch %d, rollout_num %d, LeakGAN_D%s" % (V, L, H, K, step, B, R,
+                                                                            " eval mode" if args.eval_mode else " with live dropout"),
+                      "completions_per_step": N, "feature_passes_per_step": N * (L - 1)},
+           "roofline": {"kernel": "dis_conv", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": ach / peak, "traffic": None, "flops_per_launch": conv_f * N,
+                        "avg_launch_ms": kernels["dis_conv"]["avg_ms"],
+                        "note": "every position re-scores the whole zero-padded row (the reference does the same); "
+                                "launches of 1 280 sequences do not fill the chip"},
+           "flops_per_step": {"scorer_features": feat_flops, "work2goal_projection": proj_flops},
+           "kernels": kernels}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        og = oracle.Leak(tg.synth.leak_state(V, E, H, K, 1720, B, seed=0, std=0.2), step)
+        od = oracle.Dis(tg.synth.dis_state(V, 64, *tg.synth.SEQGAN_D_FILTERS, n_out=2, seed=0))
+        s = tg.synth.tokens(1, (B, L), V)
+        u = tg.synth.uniform01(2, (1, T, L, B))
+        t0 = time.perf_counter()
+        oracle.get_reward_leakgan(og, od, s, 1, u)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": T * B / t, "unit": "completions/s", "cores": oracle.num_threads(), "kind": "port",
+                               "sample": "same workload at rollout_num 1 (%d completions, %.1f s)" % (T * B, t)}
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+
+
 def run_rollout(args, name, world, rank, dev, steps, warmup):
     """One completions/s record for WORKLOADS[name]: `warmup` untimed get_reward steps, then exactly `steps` timed ones
     between barrier + synchronize on both sides, max over ranks.  Returns the record on rank 0, None elsewhere."""
@@ -357,7 +434,9 @@ def run_rollout(args, name, world, rank, dev, steps, warmup):
                      # split-f16 kernels issue 3 fp16 MFMA products per algorithmic multiply-add: the share of the
                      # fp16 peak the matrix pipes actually deliver (the kernel is power-limited)
                      "mfma_products_per_flop": issue_factor[dom],
-                     "issued_frac": ach * issue_factor[dom] / peaks[dom]},
+                     "issued_frac": ach * issue_factor[dom] / peaks[dom],
+                     # against the measured sustained rate of the same MFMA with real operands (power-limited clock)
+                     "issued_frac_of_sustained": (ach * issue_factor[dom] / SUSTAINED_F16_MFMA_TFLOPS) if f16[dom] else None},
         "kernels": kernels,
     }
     if not args.no_cpu_baseline and world == 1:
@@ -372,12 +451,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["c5", "pg"],
+    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["c5", "pg", "leak"],
                     help="default: the headline line on configs[1] (c2, weak scaling over --gpus) carrying a `scaled` "
                          "sub-record on configs[2]'s shape (c3r8, strong scaling over --gpus); any other name: that "
                          "workload alone")
     ap.add_argument("--scaled-steps", type=int, default=None, help="timed steps of the `scaled` sub-record (default: --steps)")
     ap.add_argument("--scaled-warmup", type=int, default=None, help="warm-up steps of the `scaled` sub-record (default: --warmup)")
+    ap.add_argument("--leak-rollout-num", type=int, default=4, help="rollout_num of --workload leak (run_leakgan.py: 4)")
     ap.add_argument("--no-scaled", action="store_true", help="default workload without the `scaled` sub-record")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--eval-mode", action="store_true", help="dis.eval(): no dropout (the reference leaves it on)")
@@ -409,6 +489,10 @@ def main():
         if world > 1:
             raise SystemExit("workload pg (policy-gradient step) is a single-GPU side measurement")
         return bench_pg(args, dev)
+    if args.workload == "leak":
+        if world > 1:
+            raise SystemExit("workload leak (LeakGAN rollout) is a single-GPU side measurement")
+        return bench_leak(args, dev)
     if args.workload != "default":
         out = run_rollout(args, args.workload, world, rank, dev, args.steps, args.warmup)
     else:

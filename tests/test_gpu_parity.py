@@ -747,6 +747,5 @@ def test_pg_loss_c2_shape_against_oracle():
 def test_pg_backward_rejects_other_shapes():
     gen = tg.modules.synthetic_generator(100, 32, 64, 20, device=DEV)
     t = _t(synth.tokens(1, (4, 20), 100))
-    loss = tg.pgloss.batchPGLoss(gen, t, t, torch.ones(4, 20, device=DEV))
-    with pytest.raises(RuntimeError, match="E = H = 32"):
-        loss.backward()
+    with pytest.raises(RuntimeError, match="E = H = 32"):   # in forward, before any work is done
+        tg.pgloss.batchPGLoss(gen, t, t, torch.ones(4, 20, device=DEV))

@@ -59,31 +59,33 @@ __device__ __forceinline__ void row_ids(const LeakArgs& a, int n, int& i, int& t
 }
 
 // ---- once per call: the goal algebra's constants, fp64
-__global__ __launch_bounds__(256) void k_leak_prep(TgLeakWeights w, int B, double* prep) {
+__global__ __launch_bounds__(64) void k_leak_prep(TgLeakWeights w, int B, double* prep) {
+    // one wave per output: lanes stride over the G terms, fixed shuffle tree (the result does not depend on the grid)
     const int K = w.K, H = w.H, G = w.G;
-    const int nP = K * H, nq = K, nQ = H * H, nc = H, ns = 1, ng = B * K;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nP + nq + nQ + nc + ns + ng) return;
+    const int nP = K * H, nq = K, nQ = H * H, nc = H, ns = 1;
+    const int idx = blockIdx.x, lane = threadIdx.x;
     double acc = 0.0;
     int j = idx;
     if (j < nP) {
         const int k = j / H, h = j % H;
-        for (int o = 0; o < G; ++o) acc += (double)w.g2g_w[(size_t)k * G + o] * (double)w.m2g_w[(size_t)o * H + h];
+        for (int o = lane; o < G; o += 64) acc += (double)w.g2g_w[(size_t)k * G + o] * (double)w.m2g_w[(size_t)o * H + h];
     } else if ((j -= nP) < nq) {
-        for (int o = 0; o < G; ++o) acc += (double)w.g2g_w[(size_t)j * G + o] * (double)w.m2g_b[o];
+        for (int o = lane; o < G; o += 64) acc += (double)w.g2g_w[(size_t)j * G + o] * (double)w.m2g_b[o];
     } else if ((j -= nq) < nQ) {
         const int h1 = j / H, h2 = j % H;
-        for (int o = 0; o < G; ++o) acc += (double)w.m2g_w[(size_t)o * H + h1] * (double)w.m2g_w[(size_t)o * H + h2];
+        for (int o = lane; o < G; o += 64) acc += (double)w.m2g_w[(size_t)o * H + h1] * (double)w.m2g_w[(size_t)o * H + h2];
     } else if ((j -= nQ) < nc) {
-        for (int o = 0; o < G; ++o) acc += (double)w.m2g_w[(size_t)o * H + j] * (double)w.m2g_b[o];
+        for (int o = lane; o < G; o += 64) acc += (double)w.m2g_w[(size_t)o * H + j] * (double)w.m2g_b[o];
     } else if ((j -= nc) < ns) {
-        for (int o = 0; o < G; ++o) acc += (double)w.m2g_b[o] * (double)w.m2g_b[o];
+        for (int o = lane; o < G; o += 64) acc += (double)w.m2g_b[o] * (double)w.m2g_b[o];
     } else {
         j -= ns;
         const int b = j / K, k = j % K;
-        for (int o = 0; o < G; ++o) acc += (double)w.g2g_w[(size_t)k * G + o] * (double)w.goal_init[(size_t)b * G + o];
+        for (int o = lane; o < G; o += 64) acc += (double)w.g2g_w[(size_t)k * G + o] * (double)w.goal_init[(size_t)b * G + o];
     }
-    prep[idx] = acc;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (lane == 0) prep[idx] = acc;
 }
 
 // ---- per chunk: zero state, zero-padded feature input, rg = normalize(goal2goal(goal_init[b]))
@@ -607,7 +609,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     }
 
     const int n_prep = K * H + K + H * H + H + 1 + B * K;
-    hipLaunchKernelGGL(k_leak_prep, dim3((n_prep + 255) / 256), dim3(256), 0, stream, *g, B,
+    hipLaunchKernelGGL(k_leak_prep, dim3(n_prep), dim3(64), 0, stream, *g, B,
                        reinterpret_cast<double*>(ws + lo.prep));
     const int ci = chunk_indices(g, B, T, i_hi - i_lo);
     int prepared_n = -1;     // row count the scorer's prepared weights in ws + lo.dis were laid out for

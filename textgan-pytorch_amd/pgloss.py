@@ -24,10 +24,7 @@ class _PGLoss(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, gen, inp, target, weight, use_prob, padding_idx, *params):
-        if gen.lstm2out.in_features == 32 and gen.embeddings.embedding_dim == 32:
-            r = ops.gen_pg_forward(gen, inp, target)
-        else:  # forward value only: tg_gen_pg_backward has no kernels for other shapes and says so
-            r = ops.gen_teacher_forced(gen, inp, target, want_logp=True, want_lse=True, want_states=True)
+        r = ops.gen_pg_forward(gen, inp, target)
         logp = r["logp"]
         pred = torch.exp(logp) if use_prob else logp
         ctx.gen, ctx.use_prob, ctx.padding_idx = gen, use_prob, padding_idx
@@ -47,6 +44,13 @@ class _PGLoss(torch.autograd.Function):
 def pg_loss(gen, inp, target, weight, use_prob=False):
     """-sum(pred[n,t] * weight[n,t]); ``weight`` broadcasts against [N,L] like the reference's ``pred * reward``."""
     dev = gen.lstm2out.weight.device
+    E, H = gen.embeddings.embedding_dim, gen.lstm2out.in_features
+    if (E, H) != (32, 32):
+        # fail here, before any work: the backward kernels exist for the reference's own generator shape only, and a
+        # loss whose .backward() raises after the rollout has been paid for helps nobody
+        raise RuntimeError("textgan_hip pgloss: the policy-gradient kernels cover E = H = 32 (every SeqGAN / MaliGAN / "
+                           "SentiGAN configuration of the reference); this generator has E = %d, H = %d -- use the "
+                           "module's own batchPGLoss (autograd) for it" % (E, H))
     inp, target = inp.to(dev).long().contiguous(), target.to(dev).long().contiguous()
     if inp.dim() != 2 or inp.shape != target.shape:
         raise RuntimeError("batchPGLoss: inp and target must both be [batch, seq_len], got %s and %s"
