@@ -124,6 +124,18 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
                           float* logp_out, float* lse_out, float* logits_out,
                           float* states_out, void* stream);
 
+/* tg_gen_teacher_forced for EVERY generator shape tg_gen_supported accepts (0 or 1): shapes of class 0 run the
+ * same persistent kernel (the workspace is not touched and may be NULL); class 1 -- E, H multiples of 32 up to 1024
+ * outside the persistent kernel's set: H = 96, 160, 768, ... -- runs the pass as exact-fp32 GEMMs on
+ * v_mfma_f32_32x32x2_f32 (tg_pgw.hip: per position the gates GEMM + cell, then the projection over chunks of (t, n)
+ * rows with log-sum-exp and the target's logit per row).  Same outputs, same fp32 arithmetic contract.
+ *   workspace  tg_gen_teacher_forced_workspace_bytes(w, N, L, logits_out != NULL, states_out != NULL) bytes */
+size_t tg_gen_teacher_forced_workspace_bytes(const TgGenWeights* w, int N, int L, int have_logits_out,
+                                             int have_states_out);
+int tg_gen_teacher_forced_ws(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                             float* logp_out, float* lse_out, float* logits_out, float* states_out,
+                             void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * NLL pass: tg_gen_teacher_forced restricted to what NLL.cal_nll needs (metrics/nll.py:49-63: the log-probability
  * of each target token), honouring w->precision.  With TG_GEN_SPLIT_F16 (E = H = 32) the log-sum-exp comes from
@@ -272,7 +284,11 @@ int tg_dis_rescore_dropout(const TgDisWeights* w, const float* feature, int N,
  * The logits are recomputed tile by tile on the matrix cores; no [N*L, V] buffer exists.  fp32 throughout.
  * The embedding gradient is accumulated with float atomics (the order of additions, and so the last bit, can
  * vary between calls -- as torch's own embedding backward on a GPU); everything else is summed in fixed order.
- * Supported: E = H = 32 (every SeqGAN / MaliGAN / SentiGAN configuration of the reference); TG_ERR_ARG otherwise. */
+ * E = H = 32 (every SeqGAN / MaliGAN / SentiGAN configuration of the reference): the fused kernels of tg_pg.hip.
+ * Any other E, H (multiples of 32 up to 1024, e.g. the scaled config's 512): the same gradients as exact-fp32 GEMMs
+ * (tg_pgw.hip): the logits of <= 1 GiB worth of (t, n) rows at a time are recomputed, turned into dlogits in place
+ * and contracted three ways (dh_proj, dW_out, db_out), then L steps back through time, then the weight gradients of
+ * all steps as three large GEMMs. */
 typedef struct TgGenGrads {
     float* emb;    /* [V, E]   */
     float* w_ih;   /* [4H, E]  */
@@ -287,10 +303,13 @@ size_t tg_gen_pg_backward_workspace_bytes(const TgGenWeights* w, int N, int L);
  * tg_gen_teacher_forced writes states_out [L+1,N,2,H] (required), then the projection, lse_out [N,L] and
  * logp_out[n,t] = log_softmax(logits[n,t,:])[target[n,t]] are computed for all N*L rows side by side instead of
  * step after step (LSTMGenerator.forward models/generator.py:40-60 + the one-hot pick of models/SeqGAN_G.py:35-36).
- * Same results as tg_gen_teacher_forced to fp32 rounding.  E = H = 32 only. */
+ * Same results as tg_gen_teacher_forced to fp32 rounding.  E = H = 32: no workspace (may be NULL); other shapes run
+ * tg_gen_teacher_forced_ws's GEMM formulation in tg_gen_pg_forward_workspace_bytes(w, N, L) bytes. */
+size_t tg_gen_pg_forward_workspace_bytes(const TgGenWeights* w, int N, int L);  /* 0 for E = H = 32 */
 int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp,
                       const int64_t* target, int N, int L, float* logp_out,
-                      float* lse_out, float* states_out, void* stream);
+                      float* lse_out, float* states_out, void* workspace,
+                      size_t workspace_bytes, void* stream);
 int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
                        const int64_t* target, const float* coeff,
                        const float* lse, const float* states, int N, int L,
@@ -383,6 +402,8 @@ int tg_allgather_rows(float* raw, size_t rows_per_rank, size_t B, void* rccl_com
 #define TG_KERNEL_LEAK_DRAW 12    /* k_leak_draw                                   */
 #define TG_KERNEL_LEAK_CELLS 13   /* k_leak_cells                                  */
 #define TG_KERNEL_LEAK_PROJ 14    /* k_leak_proj                                   */
+#define TG_KERNEL_PGW_FORWARD 15  /* GEMM-path teacher-forced forward (tg_pgw.hip, one bracket)  */
+#define TG_KERNEL_PGW_BACKWARD 16 /* GEMM-path policy-gradient backward (tg_pgw.hip, one bracket) */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

@@ -157,7 +157,8 @@ PG_KEYS = ("embeddings.weight", "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.
 def pg_inputs(c):
     """(gen state_dict, inp, target, reward, use_prob, weight) of a pg_loss golden (tools/make_goldens_pg.py)."""
     V, L, B = int(c["V"]), int(c["L"]), int(c["B"])
-    sd = synth.gen_state(V, 32, 32, seed=int(c["gseed"]), std=float(c["gstd"]))
+    E, H = int(c.get("E", 32)), int(c.get("H", 32))   # goldens of round 1 carry no E / H: the reference's 32
+    sd = synth.gen_state(V, E, H, seed=int(c["gseed"]), std=float(c["gstd"]))
     target = synth.tokens(int(c["sseed"]), (B, L), V)
     inp = np.concatenate([np.full((B, 1), int(c["start_letter"]), np.int64), target[:, :-1]], 1)
     reward = synth.uniform01(int(c["rseed"]), (B, L)).astype(np.float32)
@@ -169,6 +170,8 @@ def assert_grads_close(got, want, rel=2e-5, what=""):
     """Per tensor: max |got - want| <= rel * max |want| (gradients of one tensor share a scale)."""
     for k in PG_KEYS:
         g, w = np.asarray(got[k], np.float64), np.asarray(want[k], np.float64)
+        if g.shape != w.shape and g.ndim == 2 and w.shape[1] == g.shape[1] and w.shape[0] < g.shape[0]:
+            g = g[::-(-g.shape[0] // w.shape[0])]   # the fixture keeps every n-th row of a large matrix (make_goldens_pg)
         assert g.shape == w.shape, (k, g.shape, w.shape)
         err, scale = np.abs(g - w).max(), np.abs(w).max()
         assert err <= rel * scale + 1e-9, "%s %s: max err %.3e vs scale %.3e" % (what, k, err, scale)

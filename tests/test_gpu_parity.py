@@ -692,8 +692,8 @@ def test_errors_and_cpu_inputs():
 
 # ------------------------------------------------------------------ policy-gradient loss
 def _pg_gen(c, sd):
-    g = tg.modules.LSTMGenerator(32, 32, int(c["V"]), int(c["L"]), padding_idx=int(c["padding_idx"]),
-                                 name=str(c["model"]))
+    g = tg.modules.LSTMGenerator(int(c.get("E", 32)), int(c.get("H", 32)), int(c["V"]), int(c["L"]),
+                                 padding_idx=int(c["padding_idx"]), name=str(c["model"]))
     return tg.modules.load_numpy_state(g, sd, DEV)
 
 
@@ -744,8 +744,53 @@ def test_pg_loss_c2_shape_against_oracle():
     assert loss2.item() < loss.item()  # one Adam step on the same batch lowers the loss
 
 
-def test_pg_backward_rejects_other_shapes():
-    gen = tg.modules.synthetic_generator(100, 32, 64, 20, device=DEV)
+def test_pg_loss_rejects_unsupported_shapes_in_forward():
+    gen = tg.modules.LSTMGenerator(48, 80, 100, 20).to(DEV)   # E, H not multiples of 32
     t = _t(synth.tokens(1, (4, 20), 100))
-    with pytest.raises(RuntimeError, match="E = H = 32"):   # in forward, before any work is done
+    with pytest.raises(RuntimeError, match="not supported"):   # in forward, before any work is done
         tg.pgloss.batchPGLoss(gen, t, t, torch.ones(4, 20, device=DEV))
+
+
+def test_pg_loss_wide_shape_against_oracle_and_kernels_used():
+    """A shape with ragged tiles everywhere (V, N*L, E, 4H not multiples of 128; N*L*V > one GEMM tile in every
+    dimension) through the GEMM path: loss and gradients against the oracle, the fused E = H = 32 kernels untouched."""
+    V, E, H, L, B = 1531, 96, 160, 9, 37
+    sd = synth.gen_state(V, E, H, seed=41, std=0.2)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L, name="seqgan"), sd, DEV)
+    target = synth.tokens(42, (B, L), V)
+    inp = np.concatenate([np.ones((B, 1), np.int64), target[:, :-1]], 1)
+    reward = synth.uniform01(43, (B, L)).astype(np.float32)
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+    gen.zero_grad()
+    loss.backward()
+    prof = tg._lib.profile_read()
+    tg._lib.profile_enable(False)
+    assert prof["pgw_forward"][1] == 1 and prof["pgw_backward"][1] == 1 and prof["pg_backward"][1] == 0
+    oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, reward, padding_idx=0)
+    assert loss.item() == pytest.approx(oloss, rel=1e-5)
+    _cases.assert_grads_close(_grads_of(gen), ograds, rel=5e-5, what="wide")
+
+
+@pytest.mark.parametrize("V,E,H,N,L,std", [(900, 96, 160, 33, 5, 0.2), (600, 32, 768, 5, 5, 0.05), (333, 64, 96, 130, 7, 0.3)])
+def test_teacher_forced_beyond_the_persistent_kernels(V, E, H, N, L, std):
+    """LSTMGenerator.forward (logits, log-probabilities, states) for hidden sizes outside {32, 64, 128, 256, 512}:
+    tg_gen_teacher_forced_ws runs them as exact-fp32 GEMMs; 1e-5 against the oracle like every other shape."""
+    gsd = synth.gen_state(V, E, H, seed=16, std=std)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    assert tg._lib.lib().tg_gen_supported(V, E, H) == 1
+    tgt = synth.tokens(27, (N, L), V)
+    inp = np.concatenate([np.ones((N, 1), np.int64), tgt[:, :-1]], 1)
+    o = oracle.gen_teacher_forced(og, inp, tgt, want_logits=True, want_states=True)
+    r = tg.ops.gen_teacher_forced(gen, _t(inp), _t(tgt), want_lse=True, want_logits=True, want_states=True)
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-5, atol=2e-5)
+    np.testing.assert_allclose(r["lse"].cpu().numpy(), o["lse"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["logp"].cpu().numpy(), o["logp"], rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["states"].cpu().numpy(), o["states"], rtol=1e-4, atol=5e-5)
+    # without logits_out / states_out the chunked path and the library's own state scratch are used
+    r2 = tg.ops.gen_teacher_forced(gen, _t(inp), _t(tgt), want_lse=True)
+    assert torch.equal(r2["logp"], r["logp"]) and torch.equal(r2["lse"], r["lse"])
+    lp = tg.generator.forward_logprobs(gen, _t(inp)).view(N, L, -1).cpu().numpy()
+    np.testing.assert_allclose(lp, o["logits"] - o["lse"][..., None], rtol=1e-5, atol=2e-5)

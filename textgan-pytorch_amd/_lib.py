@@ -14,6 +14,7 @@ MAX_FILTERS = 16
 MAX_OUT = 8
 
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
+           "tg_gen_teacher_forced_workspace_bytes", "tg_gen_teacher_forced_ws", "tg_gen_pg_forward_workspace_bytes",
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
            "tg_gen_sample_static_bytes", "tg_gen_sample_static",
            "tg_dis_workspace_bytes",
@@ -25,7 +26,7 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
            "dis_prefix": 6, "pg_backward": 7, "pg_forward": 8, "genw_cell": 9, "genw_proj": 10, "genw_draw": 11,
-           "leak_draw": 12, "leak_cells": 13, "leak_proj": 14}
+           "leak_draw": 12, "leak_cells": 13, "leak_proj": 14, "pgw_forward": 15, "pgw_backward": 16}
 
 
 class GenW(C.Structure):
@@ -103,7 +104,13 @@ def lib():
         l.tg_gen_nll_workspace_bytes.argtypes = [C.c_void_p, C.c_int]
         l.tg_gen_nll.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 3 + [C.c_size_t, C.c_void_p]
         l.tg_gen_nll.restype = C.c_int
-        l.tg_gen_pg_forward.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4
+        l.tg_gen_pg_forward.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 4 + [C.c_size_t, C.c_void_p]
+        l.tg_gen_pg_forward_workspace_bytes.restype = C.c_size_t
+        l.tg_gen_pg_forward_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        l.tg_gen_teacher_forced_workspace_bytes.restype = C.c_size_t
+        l.tg_gen_teacher_forced_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        l.tg_gen_teacher_forced_ws.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
+        l.tg_gen_teacher_forced_ws.restype = C.c_int
         l.tg_gen_pg_forward.restype = C.c_int
         l.tg_leak_rollout_workspace_bytes.restype = C.c_size_t
         l.tg_leak_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -160,9 +167,11 @@ default_gen_precision = "split_f16"
 default_dis_precision = "split_f16"
 
 
-def gen_weights(gen, precision=None):
+def gen_weights(gen, precision=None, teacher=False):
     """Pack the live parameters of an LSTMGenerator-shaped module (models/generator.py:33-35).
-    Read on every call: the generator is stepped between get_reward calls."""
+    Read on every call: the generator is stepped between get_reward calls.  teacher: the call is a teacher-forced /
+    policy-gradient pass, which every shape of tg_gen_supported has in fp32 (the samplers need split_f16 beyond the
+    persistent kernel's set)."""
     keep = []
     ptrs = []
     for name, p in (("embeddings.weight", gen.embeddings.weight), ("lstm.weight_ih_l0", gen.lstm.weight_ih_l0),
@@ -178,7 +187,7 @@ def gen_weights(gen, precision=None):
         raise RuntimeError("textgan_hip: generator parameter shapes are inconsistent")
     w = GenW(*ptrs, V, E, H, PRECISIONS[precision or default_gen_precision])
     sup = lib().tg_gen_supported(V, E, H)
-    if sup < 0 or (sup == 1 and (precision or default_gen_precision) != "split_f16"):
+    if sup < 0 or (sup == 1 and not teacher and (precision or default_gen_precision) != "split_f16"):
         raise RuntimeError("textgan_hip: generator shape V=%d E=%d H=%d is not supported by the compiled kernels "
                            "(every entry point: H in {32,64,128,256,512}, E a multiple of 32 up to 512; rollout / sample "
                            "/ NLL in split_f16: E, H multiples of 32 up to 1024)" % (V, E, H))

@@ -29,6 +29,7 @@
 
 #include "tg_common.h"
 #include "tg_genw.h"
+#include "tg_pgw.h"
 
 namespace {
 
@@ -1069,6 +1070,32 @@ extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, 
     a.states_out = states_out;
     a.need_proj = ((target && logp_out) || lse_out || logits_out) ? 1 : 0;
     return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
+}
+
+extern "C" size_t tg_gen_teacher_forced_workspace_bytes(const TgGenWeights* w, int N, int L, int have_logits_out,
+                                                        int have_states_out) {
+    if (!w || N < 1 || L < 1 || tg_gen_supported(w->V, w->E, w->H) != 1) return 0;
+    return tg_pgw_forward_workspace_bytes(w, N, L, have_logits_out != 0, have_states_out != 0);
+}
+
+extern "C" int tg_gen_teacher_forced_ws(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                                        float* logp_out, float* lse_out, float* logits_out, float* states_out,
+                                        void* workspace, size_t workspace_bytes, void* stream) {
+    if (!w || !w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out) {
+        tg_set_error("generator weights: null pointer");
+        return TG_ERR_ARG;
+    }
+    const int sup = tg_gen_supported(w->V, w->E, w->H);
+    if (sup == 0)
+        return tg_gen_teacher_forced(w, inp, target, N, L, logp_out, lse_out, logits_out, states_out, stream);
+    if (sup < 0) return check_weights(w);
+    if (!inp || N < 0 || L < 1 || (size_t)N * L >= ((size_t)1 << 31) - 256) {
+        tg_set_error("tg_gen_teacher_forced_ws: bad arguments (N=%d L=%d)", N, L);
+        return TG_ERR_ARG;
+    }
+    if (N == 0) return TG_OK;
+    return tg_pgw_forward(w, inp, target, N, L, logp_out, lse_out, logits_out, states_out, workspace, workspace_bytes,
+                          (hipStream_t)stream);
 }
 
 extern "C" size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w, int N) {

@@ -16,6 +16,7 @@
 // straight from registers or from a contiguous load: the k index of a product is a free permutation as long as A
 // and B agree, so "the 16 values this lane already holds" is made the k order wherever possible.
 #include "tg_common.h"
+#include "tg_pgw.h"
 
 namespace {
 
@@ -535,10 +536,28 @@ bool shape_ok(const TgGenWeights* w, int N, int L) {
 
 }  // namespace
 
+static bool pg_wide(const TgGenWeights* w) { return w && !(w->E == kHid && w->H == kHid) && tg_pgw_shape_ok(w); }
+
+extern "C" size_t tg_gen_pg_forward_workspace_bytes(const TgGenWeights* w, int N, int L) {
+    if (!pg_wide(w) || N < 1 || L < 1) return 0;
+    return tg_pgw_forward_workspace_bytes(w, N, L, false, true);
+}
+
 extern "C" int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
-                                 float* logp_out, float* lse_out, float* states_out, void* stream) {
+                                 float* logp_out, float* lse_out, float* states_out, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    if (pg_wide(w)) {  // any other E, H: exact-fp32 GEMMs (tg_pgw.hip)
+        if (!w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out || !inp || !target ||
+            !states_out || N < 0 || L < 1 || (size_t)N * L >= ((size_t)1 << 31) - 256) {
+            tg_set_error("tg_gen_pg_forward: bad arguments (N=%d L=%d; weights, inp, target and states_out are required)", N, L);
+            return TG_ERR_ARG;
+        }
+        if (N == 0) return TG_OK;
+        return tg_pgw_forward(w, inp, target, N, L, logp_out, lse_out, nullptr, states_out, workspace, workspace_bytes,
+                              (hipStream_t)stream);
+    }
     if (!w || w->E != kHid || w->H != kHid) {
-        tg_set_error("tg_gen_pg_forward: only the E = H = 32 generator is supported");
+        tg_set_error("tg_gen_pg_forward: generator shape not supported (E, H multiples of 32 up to 1024)");
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;
@@ -558,6 +577,7 @@ extern "C" int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp, cons
 }
 
 extern "C" size_t tg_gen_pg_backward_workspace_bytes(const TgGenWeights* w, int N, int L) {
+    if (pg_wide(w) && N >= 1 && L >= 1) return tg_pgw_backward_workspace_bytes(w, N, L);
     if (!shape_ok(w, N, L)) return 0;
     return make_layout(w->V, N, L).total;
 }
@@ -569,8 +589,19 @@ extern "C" int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp, con
         tg_set_error("tg_gen_pg_backward: null generator weights");
         return TG_ERR_ARG;
     }
+    if (pg_wide(w)) {  // any other E, H: exact-fp32 GEMMs (tg_pgw.hip)
+        if (N == 0) return TG_OK;
+        if (N < 0 || L < 1 || (size_t)N * L >= ((size_t)1 << 31) - 256 || !inp || !target || !coeff || !lse || !states ||
+            !grads || !grads->emb || !grads->w_ih || !grads->w_hh || !grads->b_ih || !grads->b_hh || !grads->w_out ||
+            !grads->b_out) {
+            tg_set_error("tg_gen_pg_backward: bad arguments (N=%d L=%d)", N, L);
+            return TG_ERR_ARG;
+        }
+        return tg_pgw_backward(w, inp, target, coeff, lse, states, N, L, padding_idx, grads, workspace, workspace_bytes,
+                               (hipStream_t)stream);
+    }
     if (w->E != kHid || w->H != kHid) {
-        tg_set_error("tg_gen_pg_backward: only the E = H = 32 generator is supported (got E=%d H=%d)", w->E, w->H);
+        tg_set_error("tg_gen_pg_backward: generator shape E=%d H=%d not supported (multiples of 32 up to 1024)", w->E, w->H);
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;

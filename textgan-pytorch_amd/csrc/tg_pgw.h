@@ -1,0 +1,18 @@
+// Host entry points of the GEMM-formulated generator forward / policy-gradient backward (tg_pgw.hip), called from the
+// C ABI functions in tg_gen.hip and tg_pg.hip for shapes beyond what their on-chip kernels cover.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/textgan_hip.h"
+
+bool tg_pgw_shape_ok(const TgGenWeights* w);   // E, H multiples of 32 up to 1024
+size_t tg_pgw_forward_workspace_bytes(const TgGenWeights* w, int N, int L, bool have_logits, bool have_states);
+int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L, float* logp_out,
+                   float* lse_out, float* logits_out, float* states_out, void* workspace, size_t workspace_bytes,
+                   hipStream_t stream);
+size_t tg_pgw_backward_workspace_bytes(const TgGenWeights* w, int N, int L);
+int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, const float* coeff,
+                    const float* lse, const float* states, int N, int L, int64_t padding_idx, const TgGenGrads* grads,
+                    void* workspace, size_t workspace_bytes, hipStream_t stream);

@@ -50,7 +50,7 @@ def _tokens(t, name):
 def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, want_logits=False, want_states=False):
     """tg_gen_teacher_forced: LSTMGenerator.forward over [N,L] with zero initial state
     (models/generator.py:40-60).  Returns dict(logp [N,L], lse [N,L], logits [N,L,V], states [L+1,N,2,H])."""
-    w, keep = _lib.gen_weights(gen)
+    w, keep = _lib.gen_weights(gen, teacher=True)
     inp, _ = _tokens(inp, "inp")
     N, L = inp.shape
     dev = inp.device
@@ -59,9 +59,13 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     lse = torch.empty(N, L, dtype=F32, device=dev) if want_lse else None
     logits = torch.empty(N, L, w.V, dtype=F32, device=dev) if want_logits else None
     states = torch.empty(L + 1, N, 2, w.H, dtype=F32, device=dev) if want_states else None
-    _lib.check(_lib.lib().tg_gen_teacher_forced(
+    # shapes outside the persistent kernel's set run as fp32 GEMMs and need scratch (0 bytes otherwise)
+    nbytes = _lib.lib().tg_gen_teacher_forced_workspace_bytes(C.byref(w), N, L, int(want_logits), int(want_states))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
+    _lib.check(_lib.lib().tg_gen_teacher_forced_ws(
         C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(tgt, I64, "target"), N, L,
-        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(logits), _lib.dev_ptr(states), _lib.stream_ptr()))
+        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(logits), _lib.dev_ptr(states), _lib.dev_ptr(ws), nbytes,
+        _lib.stream_ptr()))
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 
@@ -88,7 +92,7 @@ def gen_nll(gen, inp, target, precision=None, want_lse=False):
 def gen_pg_forward(gen, inp, target):
     """tg_gen_pg_forward: logp / lse / states of a teacher-forced pass, row-parallel projection (few sequences).
     Same dict as gen_teacher_forced(want_lse=True, want_states=True)."""
-    w, keep = _lib.gen_weights(gen)
+    w, keep = _lib.gen_weights(gen, teacher=True)
     inp, _ = _tokens(inp, "inp")
     target, _ = _tokens(target, "target")
     N, L = inp.shape
@@ -96,9 +100,11 @@ def gen_pg_forward(gen, inp, target):
     logp = torch.empty(N, L, dtype=F32, device=dev)
     lse = torch.empty(N, L, dtype=F32, device=dev)
     states = torch.empty(L + 1, N, 2, w.H, dtype=F32, device=dev)
+    nbytes = _lib.lib().tg_gen_pg_forward_workspace_bytes(C.byref(w), N, L)   # 0 for E = H = 32
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     _lib.check(_lib.lib().tg_gen_pg_forward(
         C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(target, I64, "target"), N, L,
-        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(states), _lib.stream_ptr()))
+        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(states), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
     return {"logp": logp, "lse": lse, "logits": None, "states": states}
 
 
@@ -107,7 +113,7 @@ def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1):
     """tg_gen_pg_backward: gradients of sum(coeff-weighted log-probabilities of the targets) with respect to the
     seven generator parameters (what autograd produces behind SeqGAN_G.batchPGLoss, models/SeqGAN_G.py:21-39).
     Returns a tuple in GenW order: (emb, w_ih, w_hh, b_ih, b_hh, w_out, b_out)."""
-    w, keep = _lib.gen_weights(gen)
+    w, keep = _lib.gen_weights(gen, teacher=True)
     inp, _ = _tokens(inp, "inp")
     target, _ = _tokens(target, "target")
     N, L = inp.shape

@@ -4,7 +4,9 @@ Drop-in for ``SeqGAN_G.batchPGLoss`` (models/SeqGAN_G.py:21-39), ``MaliGAN_G.adv
 (models/MaliGAN_G.py:21-39) and ``SentiGAN_G.batchPGLoss`` (models/SentiGAN_G.py:47-65): the returned scalar
 carries an autograd node whose backward fills ``.grad`` of the generator's seven parameters, so the instructor's
 ``self.optimize(opt, adv_loss)`` (instructor/real_data/seqgan_instructor.py:109-110) works unchanged.  Neither the
-[B*L, V] log-softmax matrix nor the [B, L, V] one-hot of the reference is ever materialised.
+[B*L, V] log-softmax matrix nor the [B, L, V] one-hot of the reference is ever materialised (E = H = 32: fused
+kernels, csrc/tg_pg.hip; any other E, H multiple of 32 up to 1024: fp32 GEMMs over <= 1 GiB of logits at a time,
+csrc/tg_pgw.hip).
 """
 import torch
 
@@ -44,13 +46,6 @@ class _PGLoss(torch.autograd.Function):
 def pg_loss(gen, inp, target, weight, use_prob=False):
     """-sum(pred[n,t] * weight[n,t]); ``weight`` broadcasts against [N,L] like the reference's ``pred * reward``."""
     dev = gen.lstm2out.weight.device
-    E, H = gen.embeddings.embedding_dim, gen.lstm2out.in_features
-    if (E, H) != (32, 32):
-        # fail here, before any work: the backward kernels exist for the reference's own generator shape only, and a
-        # loss whose .backward() raises after the rollout has been paid for helps nobody
-        raise RuntimeError("textgan_hip pgloss: the policy-gradient kernels cover E = H = 32 (every SeqGAN / MaliGAN / "
-                           "SentiGAN configuration of the reference); this generator has E = %d, H = %d -- use the "
-                           "module's own batchPGLoss (autograd) for it" % (E, H))
     inp, target = inp.to(dev).long().contiguous(), target.to(dev).long().contiguous()
     if inp.dim() != 2 or inp.shape != target.shape:
         raise RuntimeError("batchPGLoss: inp and target must both be [batch, seq_len], got %s and %s"

@@ -38,10 +38,10 @@ KEYS = ("embeddings.weight", "lstm.weight_ih_l0", "lstm.weight_hh_l0", "lstm.bia
         "lstm2out.weight", "lstm2out.bias")
 
 
-def run(name, model, V, L, B, gseed, gstd, sseed, rseed, padding_idx=0, start_letter=1):
+def run(name, model, V, L, B, gseed, gstd, sseed, rseed, padding_idx=0, start_letter=1, E=32, H=32, row_stride=1):
     cls = {"seqgan": SeqGAN_G, "maligan": MaliGAN_G, "sentigan": SentiGAN_G}[model]
-    gen = cls(32, 32, V, L, padding_idx, gpu=False)
-    sd = synth.gen_state(V, 32, 32, seed=gseed, std=gstd)
+    gen = cls(E, H, V, L, padding_idx, gpu=False)
+    sd = synth.gen_state(V, E, H, seed=gseed, std=gstd)
     gen.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()})
     target = synth.tokens(sseed, (B, L), V)
     inp = np.concatenate([np.full((B, 1), start_letter, np.int64), target[:, :-1]], 1)  # GenDataIter.prepare
@@ -52,16 +52,34 @@ def run(name, model, V, L, B, gseed, gstd, sseed, rseed, padding_idx=0, start_le
     loss.backward()
     named = dict(gen.named_parameters())
     out = {"kind": "pg_loss", "model": model, "V": V, "L": L, "B": B, "gseed": gseed, "gstd": gstd, "sseed": sseed,
-           "rseed": rseed, "padding_idx": padding_idx, "start_letter": start_letter, "loss": float(loss.item())}
+           "rseed": rseed, "padding_idx": padding_idx, "start_letter": start_letter, "loss": float(loss.item()),
+           "E": E, "H": H}
+    # large gradient matrices are stored as every row_stride-th row (the fixture stays small; the tests compare the
+    # same rows): only tensors above 200 000 elements, only for the E = H = 512 case
+    out["row_stride"] = row_stride
     for k in KEYS:
-        out["grad." + k] = named[k].grad.numpy().astype(np.float32)
+        g = named[k].grad.numpy().astype(np.float32)
+        out["grad." + k] = g[::row_stride] if (row_stride > 1 and g.ndim == 2 and g.size > 200000) else g
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
     print(name, "loss %.6f" % loss.item(), {k: float(np.abs(out["grad." + k]).max()) for k in KEYS})
 
 
 if __name__ == "__main__":
+    only = set(sys.argv[1:])
+    _run = run
+
+    def run(name, *a, **k):  # noqa: F811  (all cases, or only those named on the command line)
+        if not only or name in only:
+            _run(name, *a, **k)
+
     run("pg_tiny_seqgan", "seqgan", 77, 20, 5, 3, 0.3, 11, 12)
     run("pg_tiny_senti", "sentigan", 130, 21, 40, 4, 0.3, 13, 14)
     run("pg_tiny_mali", "maligan", 64, 20, 33, 5, 0.2, 15, 16, padding_idx=2)
     run("pg_tiny_peaked", "seqgan", 200, 20, 8, 6, 1.0, 17, 18)
     run("pg_c1_slice", "seqgan", 5000, 20, 16, 0, 0.1, 19, 20)
+    # shapes beyond E = H = 32 (the GEMM path of tg_pgw.hip): H = 64, E != H, a hidden size outside the persistent
+    # kernel's set, SentiGAN's probability form, and the scaled config's E = H = 512 at a small vocabulary
+    run("pg_h64", "seqgan", 300, 20, 9, 21, 0.3, 31, 32, E=64, H=64)
+    run("pg_e32_h96_senti", "sentigan", 210, 12, 7, 22, 0.3, 33, 34, E=32, H=96)
+    run("pg_e96_h160_mali", "maligan", 150, 10, 6, 23, 0.2, 35, 36, padding_idx=3, E=96, H=160)
+    run("pg_h512", "seqgan", 700, 8, 5, 24, 0.05, 37, 38, E=512, H=512, row_stride=16)
