@@ -60,7 +60,8 @@ def flops_model(V, L, E, H, filt, Ed=64, n_out=2):
     return conv_per_seq, conv_fresh_per_bi, hw_per_seq, gen_per_token
 
 
-PROFILE_NAME = {"gen_sample": "k_gen<true", "gen_teacher": "k_gen<false"}   # kernel symbols in rocprofv3 output
+PROFILE_NAME = {"gen_sample": "k_gen<true", "gen_teacher": "k_gen<false",   # kernel symbols in rocprofv3 output
+                "genw_proj": "k_genw_gemm<true", "genw_cell": "k_genw_gemm<false, 2, 4"}
 
 
 def pmc_traffic(workload, kernel):
