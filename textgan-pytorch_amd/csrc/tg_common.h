@@ -67,30 +67,6 @@ __device__ __forceinline__ void tg_exp16_neg(const f32x16& x, float m, float (&o
     for (int i = 0; i < 8; ++i) { out[2 * i] = e[i].x; out[2 * i + 1] = e[i].y; }
 }
 
-// 2^d in fp64 for the samplers' rescaling factors (d = a difference of two fp32 log2-domain maxima, usually in
-// [-60, 0]): k = rint(d), 2^(d-k) = exp((d-k) ln 2) as a 12-term Taylor series on |y| <= 0.347 (remainder < 2e-16),
-// scaled by ldexp.  ~16 straight-line fp64 instructions against the ~35 with branches of the library's exp2, which
-// the span-sum pass of k_gen used to execute up to 16 times per step under divergence.
-__device__ __forceinline__ double tg_exp2_f64(double d) {
-    d = d < -1100.0 ? -1100.0 : d;   // empty spans carry TG_NEG_BIG: the result underflows to exactly 0
-    const double k = __builtin_rint(d);
-    const double y = (d - k) * 0.69314718055994530942;
-    double p = 2.08767569878680989792e-9;             // 1/12!
-    p = __builtin_fma(p, y, 2.50521083854417187751e-8);  // 1/11!
-    p = __builtin_fma(p, y, 2.75573192239858906526e-7);  // 1/10!
-    p = __builtin_fma(p, y, 2.75573192239858906526e-6);  // 1/9!
-    p = __builtin_fma(p, y, 2.48015873015873015873e-5);  // 1/8!
-    p = __builtin_fma(p, y, 1.98412698412698412698e-4);  // 1/7!
-    p = __builtin_fma(p, y, 1.38888888888888888889e-3);  // 1/6!
-    p = __builtin_fma(p, y, 8.33333333333333333333e-3);  // 1/5!
-    p = __builtin_fma(p, y, 4.16666666666666666667e-2);  // 1/4!
-    p = __builtin_fma(p, y, 1.66666666666666666667e-1);  // 1/3!
-    p = __builtin_fma(p, y, 0.5);
-    p = __builtin_fma(p, y, 1.0);
-    p = __builtin_fma(p, y, 1.0);
-    return __builtin_ldexp(p, (int)k);
-}
-
 __device__ __forceinline__ float tg_sigmoid(float x) { return 1.0f / (1.0f + tg_expf(-x)); }
 
 __device__ __forceinline__ float tg_tanh(float x) {

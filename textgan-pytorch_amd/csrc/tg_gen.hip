@@ -521,19 +521,10 @@ void k_gen(const GenArgs a) {
                         const float keep = (SAMPLE && (q & gk_mask) == 0) ? 0.f : 1.f;
                         c_grp = c_grp * __builtin_amdgcn_exp2f(m_run - m_new) * keep;
                         float ev[16];
-                        if constexpr (SPLIT) {
-                            // fma(acc, inv, -m_new), one rounding, two entries per v_pk_fma_f32
-                            const f32x2 inv2 = {inv, inv}, nm2 = {-m_new, -m_new};
 #pragma unroll
-                            for (int r = 0; r < 16; r += 2) {
-                                const f32x2 v = __builtin_elementwise_fma(f32x2{acc[r], acc[r + 1]}, inv2, nm2);
-                                ev[r] = __builtin_amdgcn_exp2f(v[0]);
-                                ev[r + 1] = __builtin_amdgcn_exp2f(v[1]);
-                            }
-                        } else {
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) ev[r] = __builtin_amdgcn_exp2f(acc[r] - m_new);
-                        }
+                        for (int r = 0; r < 16; ++r)
+                            ev[r] = SPLIT ? __builtin_amdgcn_exp2f(__builtin_fmaf(acc[r], inv, -m_new))  // one rounding
+                                          : __builtin_amdgcn_exp2f(acc[r] - m_new);
                         float ts = 0.f;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) ts += ev[r];  // canonical order: sequential
@@ -676,14 +667,7 @@ void k_gen(const GenArgs a) {
                 for (int q = 0; q < 16; ++q) {
                     if (qb + q < ng_valid) {
                         const float2 r = rq[q];
-                        if constexpr (REG) {
-                            // (b2 is always set when a REG kernel samples) branch-free: the library exp2 behind the
-                            // old "max changed" test ran under divergence for almost every q
-                            fac = tg_exp2_f64((double)r.x - (double)M);
-                        } else if (r.x != fx) {
-                            fx = r.x;
-                            fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M);
-                        }
+                        if (r.x != fx) { fx = r.x; fac = b2 ? exp2((double)fx - (double)M) : exp((double)fx - (double)M); }
                         const double c = (double)r.y * fac;
                         s += c;
                         // the record is only read again by the group search below, which wants this product: leave it
