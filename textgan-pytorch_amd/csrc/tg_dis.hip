@@ -3,9 +3,12 @@
 //   k_dis_conv     embedding gather -> LDS; all filter widths as implicit GEMMs on
 //                  v_mfma_f32_32x32x2_f32 (M = filters, N = (sequence, time), K = f*Ed);
 //                  bias + ReLU + max-over-time in registers; pooled [N,F] out.
-//   k_dis_highway  h = pooled . W_hw^T as a 128x128-tiled fp32 MFMA GEMM with the sequences
-//                  on the lanes, fused sigmoid/relu gate, dropout mask and the partial
-//                  feature2out dot; partial logits [N, chunks, n_out] out.
+//                  Split-fp16 arithmetic (default): operands as (hi, lo) fp16 pairs on
+//                  v_mfma_f32_32x32x16_f16, pooled features out as the highway GEMM's B pieces.
+//   k_dis_highway_frag  h = pooled . W_hw^T on fragment-ordered split-fp16 operands: persistent,
+//                  XCD-aware, LDS-DMA double buffered; fused sigmoid/relu gate, dropout mask and
+//                  the partial feature2out dot; partial logits [N, slots, n_out] out.
+//   k_dis_highway  the same stage in exact fp32 (TG_DIS_FP32, or F % 8 != 0): 128x128 tiles.
 //   k_dis_final    fixed-order sum of the partials + bias, softmax column -> reward.
 //
 // Replaces models/discriminator.py:40-64 and utils/rollout.py:146-148 of the reference.
@@ -64,7 +67,10 @@ struct ConvArgs {
     // its lo part n_k*f_k*64 halves later; scales = {scale_w, scale_e, 1/(scale_w*scale_e)} on the device
     const _Float16* w16;
     const float* scales;
-    unsigned* pooled_absmax;   // nullable: max of the pooled features as ordered bits (they are >= 0), for the highway's scale
+    _Float16* pfrag;           // nullable (split path, F % 8 == 0): the pooled features go out as the highway GEMM's B
+                               // fragments [seq/32][KBp][hi|lo][64 lanes] x 8 halves, scaled by scales[5], instead of
+                               // the fp32 matrix pooled[N,F]
+    int KBp;                   // 16-feature k blocks per sequence block in pfrag
     int woff[TG_MAX_FILTERS];
     int n_merged;              // mixed-width remainder tiles (items with k == 0xFF, mt = tile index); split path only
     int pad_rows;              // zero rows kept after the sequence in LDS: max (fmax - fmin) over the merged tiles
@@ -79,6 +85,32 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 constexpr int kERowH = 2 * kERow;  // LDS halves per embedded token in the split path: [64 hi | 64 lo | 8 pad]
 #define TG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+// Pooled features -> the highway GEMM's B operand in fragment order (k_dis_highway_frag): piece
+// ((seq/32 * KB + f/16) * 2 + part) * 64 + lane, lane = seq%32 + 32*((f/8)&1), holding features 8*(f/8) .. +7 of that
+// sequence as 8 halves (part 0: hi = fp16(x*sP), part 1: lo = fp16(x*sP - hi)).  The conv epilogue holds 4 consecutive
+// features per lane (f % 4 == 0): half a piece, one 8-byte store per part.
+__device__ __forceinline__ void pf_store4(_Float16* pf, int KB, int seq, int f, const float (&o)[4], float sP) {
+    f16x4 h, l;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float x = o[e] * sP;
+        h[e] = (_Float16)x;
+        l[e] = (_Float16)(x - (float)h[e]);
+    }
+    const size_t piece = (((size_t)(seq >> 5) * KB + (f >> 4)) * 2) * 64 + (seq & 31) + 32 * ((f >> 3) & 1);
+    f16x4* d = reinterpret_cast<f16x4*>(pf + piece * 8) + ((f >> 2) & 1);
+    d[0] = h;
+    d[128] = l;  // the lo piece: 64 pieces = 128 f16x4 further
+}
+__device__ __forceinline__ void pf_store1(_Float16* pf, int KB, int seq, int f, float v, float sP) {
+    const float x = v * sP;
+    const _Float16 h = (_Float16)x;
+    const size_t piece = (((size_t)(seq >> 5) * KB + (f >> 4)) * 2) * 64 + (seq & 31) + 32 * ((f >> 3) & 1);
+    _Float16* d = pf + piece * 8 + (f & 7);
+    d[0] = h;
+    d[512] = (_Float16)(x - (float)h);
+}
 
 // SPLIT = false: exact fp32 on v_mfma_f32_32x32x2_f32.
 // SPLIT = true:  x = hi + lo with hi = fp16(x*scale), lo = fp16(x*scale - hi) (22 mantissa bits; scale a power of
@@ -164,7 +196,6 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         g_min = __builtin_amdgcn_readfirstlane(g_min);
     }
 
-    float pmax = 0.f;  // largest pooled value this lane stored
     const long long st1 = tg_clock();
     long long st_mfma = 0;
     int st_items = 0;
@@ -352,8 +383,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                     float o = __builtin_fmaxf(runmax[r] + mm->bias[mrow(r)], 0.f);
                     if (MODE == kConvPrefix && g_lane >= fwr)
                         o = __builtin_fmaxf(o, a.cv[((size_t)b_lane * L + (g_lane - fwr)) * a.w.F + ft]);
-                    po[ft] = o;
-                    pmax = __builtin_fmaxf(pmax, o);
+                    if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, ft, o, a.scales[5]);
+                    else po[ft] = o;
                 }
             }
             continue;
@@ -377,18 +408,21 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(o[e], pv[e]);
                     }
-                    *reinterpret_cast<f32x4*>(po + m0) = o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) pmax = __builtin_fmaxf(pmax, o[e]);
+                    if (SPLIT && a.pfrag) {
+                        const float o4[4] = {o[0], o[1], o[2], o[3]};
+                        pf_store4(a.pfrag, a.KBp, seq0 + s, a.foff[k] + m0, o4, a.scales[5]);
+                    } else {
+                        *reinterpret_cast<f32x4*>(po + m0) = o;
+                    }
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         if (m0 + e < nk) {
                             float o = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
                             if (pm) o = __builtin_fmaxf(o, pm[m0 + e]);
-                            po[m0 + e] = o;
-                            pmax = __builtin_fmaxf(pmax, o);
-                        }
+                            if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, a.foff[k] + m0 + e, o, a.scales[5]);
+                            else po[m0 + e] = o;
+                                }
                 }
             }
         }
@@ -397,16 +431,6 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         const long long st2 = tg_clock();
         long long* o = a.stamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 4;
         o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st_mfma; o[3] = st_items;
-    }
-    if (MODE != kConvStoreAll && a.pooled_absmax) {  // one atomic per workgroup
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) pmax = __builtin_fmaxf(pmax, __shfl_xor(pmax, off, 64));
-        __syncthreads();  // every wave is out of the item loop: the counter word is free
-        if (tid == 0) *ctr = 0;
-        __syncthreads();
-        if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(ctr), __float_as_uint(pmax));
-        __syncthreads();
-        if (tid == 0 && *ctr) atomicMax(a.pooled_absmax, (unsigned)*ctr);
     }
 }
 
@@ -536,32 +560,6 @@ __global__ __launch_bounds__(256) void k_absmax_banks(const SplitArgs a, unsigne
     for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256)
         m = max(m, __float_as_uint(a.src[k][i]) & 0x7fffffffu);
     block_atomic_max(m, out);
-}
-
-__global__ __launch_bounds__(256) void k_split(const float* src, size_t n, _Float16* hi, _Float16* lo,
-                                               const float* scale) {
-    const float sc = *scale;
-    for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * 1024) {
-        if (i + 4 <= n) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + i);
-            f16x4 h, l;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x = v[e] * sc;
-                h[e] = (_Float16)x;
-                l[e] = (_Float16)(x - (float)h[e]);
-            }
-            *reinterpret_cast<f16x4*>(hi + i) = h;
-            *reinterpret_cast<f16x4*>(lo + i) = l;
-        } else {
-            for (size_t j = i; j < n; ++j) {
-                const float x = src[j] * sc;
-                const _Float16 h = (_Float16)x;
-                hi[j] = h;
-                lo[j] = (_Float16)(x - (float)h);
-            }
-        }
-    }
 }
 
 // Running max over time of the sentences' window values: cv[b][t][f] <- max_{t' <= t} cv[b][t'][f]
@@ -696,254 +694,6 @@ __global__ __launch_bounds__(kHwThreads) __attribute__((amdgpu_waves_per_eu(2, 2
     hw_epilogue<2, kHwTile>(a, acc, red, 2, f0, s0, bn, wm, wn, n, hh, tid);
 }
 
-// ---- highway GEMM on split-fp16 operands (TG_DIS_SPLIT_F16): W_hw pre-split into (hi, lo) halves by k_split, the
-// pooled features split while they are staged into LDS (they are read as fp32 either way: no extra pass, no copy)
-constexpr int kHsBK = 64;              // halves per tile row
-constexpr int kHsStride = kHsBK + 8;   // 144-B rows: 9 16-B slots (odd) -> conflict-free ds_read_b128
-struct HsArgs {
-    HwArgs h;
-    const _Float16* w_hi;   // [F,F] scaled hw_w, lo part F*F halves later
-    const float* scales;    // {scale_w, scale_p, 1/(scale_w*scale_p)}
-};
-
-struct HsStage { f16x8 v[4]; };
-template <int NT>
-__device__ __forceinline__ void hs_fetch(HsStage& st, const _Float16* src, int row0, int nrows, int k0, int F, int tid) {
-    const int c = tid & 7, r0 = tid >> 3;  // 8 chunks of 8 halves per row, NT/8 rows per pass
-    const int k = k0 + 8 * c;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = tg_min(row0 + r0 + (NT / 8) * i, nrows - 1);
-        f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (k < F) v = *reinterpret_cast<const f16x8*>(src + (size_t)row * F + k);
-        st.v[i] = v;
-    }
-}
-template <int NT>
-__device__ __forceinline__ void hs_commit(const HsStage& st, _Float16* dst, int tid) {
-    const int c = tid & 7, r0 = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f16x8*>(dst + (r0 + (NT / 8) * i) * kHsStride + 8 * c) = st.v[i];
-}
-// the fp32 operand (pooled): same tile shape, 8 floats per (row, chunk)
-struct HsStageF { f32x4 v[4][2]; };
-template <int NT>
-__device__ __forceinline__ void hs_fetch_f32(HsStageF& st, const float* src, int row0, int nrows, int k0, int F, int tid) {
-    const int c = tid & 7, r0 = tid >> 3;
-    const int k = k0 + 8 * c;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = tg_min(row0 + r0 + (NT / 8) * i, nrows - 1);
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        st.v[i][0] = z;
-        st.v[i][1] = z;
-        if (k < F) {
-            const f32x4* p = reinterpret_cast<const f32x4*>(src + (size_t)row * F + k);
-            st.v[i][0] = p[0];
-            st.v[i][1] = p[1];
-        }
-    }
-}
-template <int NT>
-__device__ __forceinline__ void hs_commit_split(const HsStageF& st, _Float16* hi, _Float16* lo, float sc, int tid) {
-    const int c = tid & 7, r0 = tid >> 3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f16x8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float x = st.v[i][e >> 2][e & 3] * sc;
-            h[e] = (_Float16)x;
-            l[e] = (_Float16)(x - (float)h[e]);
-        }
-        *reinterpret_cast<f16x8*>(hi + (r0 + (NT / 8) * i) * kHsStride + 8 * c) = h;
-        *reinterpret_cast<f16x8*>(lo + (r0 + (NT / 8) * i) * kHsStride + 8 * c) = l;
-    }
-}
-
-// Epilogue of the split kernel (F % 8 == 0): the accumulators (h without its bias) go through LDS so that the
-// element-wise part runs row-major -- 32 consecutive threads own one sequence row of the tile, 4 features each:
-// pooled / dropout reads and the feature store are 512-B contiguous per row instead of 16-B pieces of 64 rows per
-// instruction, and with the accumulators dead every thread's loads (all its rows) are in flight before the first use.
-template <int NJ, int TF, int TS, int NT, class ARGS>
-__device__ __forceinline__ void hw_epilogue_rows(const ARGS& a, f32x16 (&acc)[2][NJ], float* ht, int f0, int s0, int bn,
-                                                 int wm, int wn, int n, int hh, int tid) {
-    constexpr int HS = TF + 4;            // h tile row stride (floats)
-    constexpr int RP = NT / (TF / 4);     // rows per pass
-    constexpr int NP = TS / RP;           // passes
-    static_assert(TF / 4 == 32, "one row = 32 threads (the reduction below is over 32 lanes)");
-    const int F = a.w.F, n_out = a.w.n_out;
-#pragma unroll
-    for (int jn = 0; jn < NJ; ++jn)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                float* d = ht + (wn * (32 * NJ) + jn * 32 + n) * HS + wm * 64 + i * 32 + 8 * rq + 4 * hh;
-                *reinterpret_cast<f32x4*>(d) =
-                    f32x4{acc[i][jn][4 * rq], acc[i][jn][4 * rq + 1], acc[i][jn][4 * rq + 2], acc[i][jn][4 * rq + 3]};
-            }
-    __syncthreads();
-    const int c4 = tid & 31, r8 = tid >> 5;
-    const int fb = f0 + 4 * c4;           // this thread's 4 features (all inside or all outside F: F % 4 == 0)
-    const bool fin = fb < F;
-    f32x4 pv[NP], uv[NP];
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int seqc = tg_min(s0 + p * RP + r8, a.N - 1);
-        const size_t o4 = (size_t)seqc * F + fb;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        pv[p] = z;
-        uv[p] = z;
-        if (fin) {
-            pv[p] = *reinterpret_cast<const f32x4*>(a.pooled + o4);
-            if (a.dropout_u) uv[p] = *reinterpret_cast<const f32x4*>(a.dropout_u + o4);
-        }
-    }
-    float hb4[4], ow[kMaxOut][4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        hb4[e] = fin ? a.w.hw_b[fb + e] : 0.f;
-#pragma unroll
-        for (int o = 0; o < kMaxOut; ++o) ow[o][e] = (fin && o < n_out) ? a.w.out_w[(size_t)o * F + fb + e] : 0.f;
-    }
-#pragma unroll
-    for (int p = 0; p < NP; ++p) {
-        const int row = p * RP + r8;
-        const int seq = s0 + row;
-        const f32x4 hv = *reinterpret_cast<const f32x4*>(ht + row * HS + 4 * c4);
-        float fv[4], part[kMaxOut];
-#pragma unroll
-        for (int o = 0; o < kMaxOut; ++o) part[o] = 0.f;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float h = hv[e] + hb4[e];
-            const float sg = tg_sigmoid(h);
-            fv[e] = sg * __builtin_fmaxf(h, 0.f) + (1.f - sg) * pv[p][e];
-        }
-        if (a.feature_out && fin && seq < a.N)
-            *reinterpret_cast<f32x4*>(a.feature_out + (size_t)seq * F + fb) = f32x4{fv[0], fv[1], fv[2], fv[3]};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float d = fin ? fv[e] : 0.f;
-            if (a.dropout_u) d = (uv[p][e] < a.keep) ? d * a.scale : 0.f;
-            else if (a.drop_gen)
-                d = tg_drop_keep((uint32_t)seq * (uint32_t)F + (uint32_t)(fb + e), a.drop_seed, a.keep_u32) ? d * a.scale : 0.f;
-#pragma unroll
-            for (int o = 0; o < kMaxOut; ++o)
-                if (o < n_out) part[o] = __builtin_fmaf(d, ow[o][e], part[o]);
-        }
-        // fixed tree over the row's 32 threads
-#pragma unroll
-        for (int o = 0; o < kMaxOut; ++o) {
-            if (o < n_out) {
-#pragma unroll
-                for (int off = 1; off < 32; off <<= 1) part[o] += __shfl_xor(part[o], off, 64);
-            }
-        }
-        if (c4 == 0 && seq < a.N) {
-            float* po = a.partial + ((size_t)seq * a.nchunk + bn) * kMaxOut;
-#pragma unroll
-            for (int o = 0; o < kMaxOut; ++o)
-                if (o < n_out) po[o] = part[o];
-        }
-    }
-}
-
-// Workgroup tile = (64*WF features) x (32*NJ*WS sequences), one wave per (feature group, sequence group), 2 x NJ
-// accumulators of 32 x 32 per wave.  Used as <2,2,2>: 128 x 128, 256 threads, two workgroups per CU.
-template <int WF, int WS, int NJ>
-__global__ __launch_bounds__(64 * WF * WS) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void k_dis_highway_split(const HsArgs a) {
-    constexpr int TF = 64 * WF, TS = 32 * NJ * WS, NT = 64 * WF * WS;
-    static_assert(TF * 8 == NT * 4 && TS * 8 == NT * 4, "fetch helpers: 4 passes of NT/8 rows cover a tile");
-    // operand tiles (hi, lo of both); the epilogue's cross-wave partials reuse the space
-    extern __shared__ __attribute__((aligned(16))) _Float16 tiles[];
-    _Float16* Ah = tiles;
-    _Float16* Al = Ah + TF * kHsStride;
-    _Float16* Bh = Al + TF * kHsStride;
-    _Float16* Bl = Bh + TS * kHsStride;
-    static_assert(sizeof(float) * TS * (TF + 4) <= sizeof(_Float16) * 2 * (TF + TS) * kHsStride, "h tile must fit");
-
-    const int F = a.h.w.F;
-    const int tid = threadIdx.x;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wv / WS, wn = wv % WS;
-    const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
-    // Persistent workgroups, dealt to the 8 XCDs round-robin by blockIdx.  XCD x owns the sequence tiles bm = x (mod 8)
-    // and its workgroups walk that list -- all feature chunks of a tile, then the next tile -- in strides of the
-    // XCD's workgroup count.  Every tile costs the same, so the workgroups of an XCD stay within a k-step or two of
-    // each other and the operand slices they share (a pooled tile 14 ways, a W_hw slab ~4 ways) are served by that
-    // XCD's L2; dispatched one tile per workgroup they drift apart and the L2 thrashes (6.7 GB fetched per launch).
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
-    const int njx = ((a.h.nseqtile - xcd + 7) >> 3) * a.h.nchunk;  // work items of this XCD
-    const size_t wlo = (size_t)F * F;
-    const float sp = a.scales[1];
-    for (int jx = slot; jx < njx; jx += nslot) {
-    const int bn = jx % a.h.nchunk, bm = (jx / a.h.nchunk) * 8 + xcd;
-    const int f0 = bn * TF, s0 = bm * TS;
-
-    f32x16 acc[2][NJ];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    HsStage sah, sal;
-    HsStageF sb;
-    hs_fetch<NT>(sah, a.w_hi, f0, F, 0, F, tid);
-    hs_fetch<NT>(sal, a.w_hi + wlo, f0, F, 0, F, tid);
-    hs_fetch_f32<NT>(sb, a.h.pooled, s0, a.h.N, 0, F, tid);
-    for (int k0 = 0; k0 < F; k0 += kHsBK) {
-        __syncthreads();
-        hs_commit<NT>(sah, Ah, tid);
-        hs_commit<NT>(sal, Al, tid);
-        hs_commit_split<NT>(sb, Bh, Bl, sp, tid);
-        __syncthreads();
-        if (k0 + kHsBK < F) {
-            hs_fetch<NT>(sah, a.w_hi, f0, F, k0 + kHsBK, F, tid);
-            hs_fetch<NT>(sal, a.w_hi + wlo, f0, F, k0 + kHsBK, F, tid);
-            hs_fetch_f32<NT>(sb, a.h.pooled, s0, a.h.N, k0 + kHsBK, F, tid);
-        }
-#pragma unroll
-        for (int ks = 0; ks < kHsBK / 16; ++ks) {
-            f16x8 ah[2], al[2], bh[NJ], bl[NJ];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ao = (wm * 64 + i * 32 + n) * kHsStride + 16 * ks + 8 * hh;
-                ah[i] = *reinterpret_cast<const f16x8*>(Ah + ao);
-                al[i] = *reinterpret_cast<const f16x8*>(Al + ao);
-            }
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int bo = (wn * (32 * NJ) + j * 32 + n) * kHsStride + 16 * ks + 8 * hh;
-                bh[j] = *reinterpret_cast<const f16x8*>(Bh + bo);
-                bl[j] = *reinterpret_cast<const f16x8*>(Bl + bo);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int jn = 0; jn < NJ; ++jn) {
-                    acc[i][jn] = TG_MFMA16(ah[i], bh[jn], acc[i][jn]);
-                    acc[i][jn] = TG_MFMA16(ah[i], bl[jn], acc[i][jn]);
-                    acc[i][jn] = TG_MFMA16(al[i], bh[jn], acc[i][jn]);
-                }
-        }
-    }
-    const float inv = a.scales[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] *= inv;
-    __syncthreads();  // the last tile's reads are done before the epilogue reuses the space
-    hw_epilogue_rows<NJ, TF, TS, NT>(a.h, acc, reinterpret_cast<float*>(tiles), f0, s0, bn, wm, wn, n, hh, tid);
-    }
-}
-
 template <int NJ, int TS, class ARGS>
 __device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][NJ], float (*red)[TS][kMaxOut], int nwm,
                                             int f0, int s0, int bn, int wm, int wn, int n, int hh, int tid) {
@@ -1034,6 +784,276 @@ __device__ __forceinline__ void hw_epilogue(const ARGS& a, f32x16 (&acc)[2][NJ],
             }
         }
     }
+}
+
+// ---- highway GEMM on fragment-ordered split-fp16 operands (r02): the structure of the generator's vocabulary GEMM
+// (tg_genw.hip k_genw_gemm).  A = W_hw as pieces [feature/32][KB][hi|lo][lane] (k_hw_make_frag, once per call),
+// B = the pooled features as pieces [seq/32][KB][hi|lo][lane] written by the conv epilogue itself (pf_store4): no
+// operand is transposed, converted or padded inside the GEMM, every stage is a linear copy made by LDS-DMA
+// (global_load_lds_dwordx4, no staging registers), every ds_read_b128 a conflict-free 1-KiB row.  K = F padded to a
+// multiple of 32 (zero pieces), stages of 32 through two LDS buffers, one barrier per stage.  Workgroups are
+// persistent and walk their XCD's tile list (8 row tiles per A tile group), so the W_hw slab of a feature tile is
+// fetched once per XCD pass instead of once per 128 sequences.
+// Epilogue per (32 features x 32 sequences) accumulator: h = acc/(sW sP) + b; gate sigma(h) relu(h) + (1 - sigma(h))
+// pooled with pooled = (hi + lo)/sP read back from the B pieces (8 bytes per lane and 4 features); dropout;
+// partial feature2out dot, summed over the wave's features in a fixed order -> partial[seq][chunk][o].
+struct Hw2Args {
+    HwArgs h;            // weights, dropout, outputs (h.pooled unused)
+    const f32x4* Wf;     // [MB][KB][2][64]
+    const f32x4* Pf;     // [RB][KB][2][64]
+    int KB;              // 16-wide k blocks (even)
+    int MT, RT, NB;      // feature tiles, sequence tiles of the workgroup shape; logical tiles 8 * MT * ceil(RT / 8)
+    const float* scales; // [4] sW, [5] sP, [6] 1/(sW sP), [7] 1/sP
+};
+
+__device__ __forceinline__ void hw_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_dis_highway_frag(const Hw2Args a) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int MBT = WM * TM, RBT = WN * TN;
+    constexpr int NLA = MBT * 256 / NTHR, NLB = RBT * 256 / NTHR;
+    constexpr int STAGE = (MBT + RBT) * 256;
+    extern __shared__ __attribute__((aligned(16))) f32x4 hlds[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wm = w / WN, wn = w % WN;
+    const int per_xcd = a.NB >> 3, stride = gridDim.x >> 3;
+    const int lb_end = ((int)blockIdx.x & 7) * per_xcd + per_xcd;
+    const int per = 8 * a.MT;
+    auto decode = [&](int lb, int& mb0, int& rb0) {
+        const int rtg = lb / per, rem = lb - rtg * per;
+        const int rt = rtg * 8 + (rem & 7);
+        mb0 = MBT * (rem >> 3);
+        rb0 = RBT * rt;
+        return rt < a.RT;
+    };
+    auto next_valid = [&](int lb, int& mb0, int& rb0) {
+        while (lb < lb_end && !decode(lb, mb0, rb0)) lb += stride;
+        return lb;
+    };
+    int mb0 = 0, rb0 = 0;
+    int lb = next_valid(((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3), mb0, rb0);
+    if (lb >= lb_end) return;
+    const int S = a.KB >> 1;
+    const int pw = tid & 255;
+    auto load_stage = [&](int mb, int rb, int s, int buf) {
+        f32x4* d = hlds + buf * STAGE + tid;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i)
+            hw_glds16(a.Wf + ((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw, d + i * NTHR);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            hw_glds16(a.Pf + ((size_t)(rb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw, d + MBT * 256 + i * NTHR);
+    };
+    f32x16 acc[TM][TN];
+    load_stage(mb0, rb0, 0, 0);
+    __syncthreads();
+    int gs = 0;
+    for (;;) {
+        int nmb0 = 0, nrb0 = 0;
+        const int nlb = next_valid(lb + stride, nmb0, nrb0);
+        const bool has_next = nlb < lb_end;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int s = 0; s < S; ++s, ++gs) {
+            if (s + 1 < S) load_stage(mb0, rb0, s + 1, (gs + 1) & 1);
+            else if (has_next) load_stage(nmb0, nrb0, 0, (gs + 1) & 1);
+            const f32x4* la = hlds + (gs & 1) * STAGE + (TM * wm) * 256 + lane;
+            const f32x4* lbp = hlds + (gs & 1) * STAGE + MBT * 256 + (TN * wn) * 256 + lane;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    bh[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128]);
+                    bl[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128 + 64]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128]);
+                    al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(al[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bl[ni], acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+
+        // ---- epilogue of this wave: feature blocks mbw .. mbw+TM-1, sequence blocks rbw .. rbw+TN-1
+        {
+            const int F = a.h.w.F, n_out = a.h.w.n_out;
+            const float inv = a.scales[6], invP = a.scales[7];
+            const int mbw = mb0 + TM * wm, rbw = rb0 + TN * wn;
+            // partial slots are per 64 features whatever the tile shape: shards of a call (other N, maybe the other
+            // tile shape) then sum their logits in the same order and stay bit-identical to the unsharded call
+            static_assert(TM % 2 == 0, "two feature blocks per partial slot");
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int rb = rbw + ni;
+                const int seq = rb * 32 + n;
+#pragma unroll
+                for (int sl = 0; sl < TM / 2; ++sl) {
+                    float part[kMaxOut];
+#pragma unroll
+                    for (int o = 0; o < kMaxOut; ++o) part[o] = 0.f;
+#pragma unroll
+                    for (int m2 = 0; m2 < 2; ++m2) {
+                        const int mi = 2 * sl + m2;
+                        const int mb = mbw + mi;
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq) {
+                            const int fb = 32 * mb + 8 * rq + 4 * hh;   // 4 consecutive features (F % 8 == 0: all in or all out)
+                            if (fb >= F) continue;
+                            // pooled[seq][fb .. fb+3] from the B pieces: k block 2*mb + (rq >> 1), lane n + 32*(rq & 1), half hh
+                            const _Float16* pp = reinterpret_cast<const _Float16*>(a.Pf) +
+                                                 ((((size_t)rb * a.KB + 2 * mb + (rq >> 1)) * 2) * 64 + n + 32 * (rq & 1)) * 8 + 4 * hh;
+                            const f16x4 ph = *reinterpret_cast<const f16x4*>(pp);
+                            const f16x4 pl = *reinterpret_cast<const f16x4*>(pp + 512);
+                            const f32x4 hb = *reinterpret_cast<const f32x4*>(a.h.w.hw_b + fb);
+                            float fv[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float pooled = ((float)ph[e] + (float)pl[e]) * invP;
+                                const float h = __builtin_fmaf(acc[mi][ni][4 * rq + e], inv, hb[e]);
+                                const float sg = tg_sigmoid(h);
+                                fv[e] = sg * __builtin_fmaxf(h, 0.f) + (1.f - sg) * pooled;
+                            }
+                            if (seq < a.h.N) {
+                                const size_t o4 = (size_t)seq * F + fb;
+                                if (a.h.feature_out)
+                                    *reinterpret_cast<f32x4*>(a.h.feature_out + o4) = f32x4{fv[0], fv[1], fv[2], fv[3]};
+                                if (a.h.dropout_u) {
+                                    const f32x4 u = *reinterpret_cast<const f32x4*>(a.h.dropout_u + o4);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) fv[e] = (u[e] < a.h.keep) ? fv[e] * a.h.scale : 0.f;
+                                } else if (a.h.drop_gen) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        fv[e] = tg_drop_keep((uint32_t)seq * (uint32_t)F + (uint32_t)(fb + e), a.h.drop_seed, a.h.keep_u32)
+                                                    ? fv[e] * a.h.scale : 0.f;
+                                }
+                            }
+#pragma unroll
+                            for (int o = 0; o < kMaxOut; ++o) {
+                                if (o < n_out) {
+                                    const f32x4 ow = *reinterpret_cast<const f32x4*>(a.h.w.out_w + (size_t)o * F + fb);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) part[o] = __builtin_fmaf(fv[e], ow[e], part[o]);
+                                }
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int o = 0; o < kMaxOut; ++o) part[o] += __shfl_xor(part[o], 32, 64);   // the two feature halves of a row
+                    if (hh == 0 && seq < a.h.N) {
+                        float* po = a.h.partial + ((size_t)seq * a.h.nchunk + (mbw >> 1) + sl) * kMaxOut;
+#pragma unroll
+                        for (int o = 0; o < kMaxOut; ++o)
+                            if (o < n_out) po[o] = part[o];
+                    }
+                }
+            }
+        }
+        if (!has_next) break;
+        lb = nlb;
+        mb0 = nmb0;
+        rb0 = nrb0;
+    }
+}
+
+// W_hw -> A pieces: piece ((mb*KB + kb)*2 + part)*64 + lane = W_hw[32mb + lane%32][16kb + 8(lane/32) + 0..7] * sW as
+// 8 halves (hi or lo); rows / columns past F are zero.
+__global__ __launch_bounds__(256) void k_hw_make_frag(const float* __restrict__ hw_w, int F, int MB, int KB,
+                                                      const float* scales, f16x8* __restrict__ Wf) {
+    const float sW = scales[4];
+    const long total = (long)MB * KB * 128;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
+        const long q = i >> 7;
+        const int kb = (int)(q % KB), mb = (int)(q / KB);
+        const int row = 32 * mb + (lane & 31), k0 = 16 * kb + 8 * (lane >> 5);
+        f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (row < F) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (k0 + e < F) {
+                    const float x = hw_w[(size_t)row * F + k0 + e] * sW;
+                    const _Float16 h = (_Float16)x;
+                    o[e] = part ? (_Float16)(x - (float)h) : h;
+                }
+            }
+        }
+        Wf[i] = o;
+    }
+}
+
+// pieces of the pooled fragments whose features lie past F (the k padding up to a multiple of 32): zero, so that the
+// GEMM meets 0 . 0 there and not whatever the workspace held
+__global__ __launch_bounds__(256) void k_pf_zero_pad(f16x8* __restrict__ Pf, int RB, int KB, int F) {
+    const int kb_first = F >> 4;   // first k block with a feature >= F (F % 8 == 0)
+    const int nkb = KB - kb_first;
+    const long total = (long)RB * nkb * 128;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
+        const long q = i >> 7;
+        const int kb = kb_first + (int)(q % nkb);
+        const long rb = q / nkb;
+        if (16 * kb + 8 * (lane >> 5) >= F) Pf[((rb * KB + kb) * 2 + part) * 64 + lane] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+}
+
+// |max| of all conv biases -> out (one workgroup)
+__global__ __launch_bounds__(256) void k_absmax_bias(const TgDisWeights w, unsigned* out) {
+    unsigned m = 0;
+    for (int k = 0; k < w.n_filters; ++k)
+        for (int i = threadIdx.x; i < w.n[k]; i += 256) m = max(m, __float_as_uint(w.conv_b[k][i]) & 0x7fffffffu);
+    block_atomic_max(m, out);
+}
+
+// Scales of the fragment highway, all known before the conv runs: sW from |max| of W_hw (absmax[2]); sP from a BOUND
+// on the pooled features, |conv| <= 64 f_max max|w| max|e| + max|b| (absmax[0], [1], [3]) -- the conv epilogue splits
+// its outputs with it, so it cannot wait for their actual maximum.  fp16 is a floating format: an over-estimate by
+// 2^10 still leaves the (hi, lo) pair 22 significant bits for every feature within 2^-6 of the largest.
+__global__ void k_make_scales_hw(const unsigned* absmax, float* scales, int fmax) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto pow2_for = [](float m) {
+        int ex = 0;
+        float sc = 1.f;
+        if (m > 0.f && m < __builtin_inff()) {
+            (void)frexpf(m, &ex);
+            sc = ldexpf(1.f, 14 - ex);
+        }
+        return sc;
+    };
+    const float sW = pow2_for(__uint_as_float(absmax[2]));
+    const float bound = 64.f * (float)fmax * __uint_as_float(absmax[0]) * __uint_as_float(absmax[1]) + __uint_as_float(absmax[3]);
+    const float sP = pow2_for(bound);
+    scales[4] = sW;
+    scales[5] = sP;
+    scales[6] = 1.f / (sW * sP);
+    scales[7] = 1.f / sP;
 }
 
 struct FinalArgs {
@@ -1239,22 +1259,38 @@ size_t conv_weight_count(const TgDisWeights* w) {  // (hi, lo) pairs, merged til
     return n + kMaxMerged * (merged_frag_halves(fmax) / 2 + sizeof(MergedMeta) / 4 + 64);
 }
 
+// fragment highway geometry: k blocks of 16 (an even count), feature blocks of 32 padded to the 256-wide tile, sequence
+// blocks of 32 padded to 256 sequences
+inline int hw_kb(int F) { return 2 * ((F + 31) / 32); }
+inline int hw_mb(int F) { return ((F + 255) / 256) * 8; }
+inline size_t hw_rb(int N) { return ((size_t)N + 255) / 256 * 8; }
+inline size_t pooled_bytes(const TgDisWeights* w, int N) {   // fp32 [N,F] or the B pieces, whichever is larger
+    const size_t a = sizeof(float) * (size_t)N * w->F, b = hw_rb(N) * hw_kb(w->F) * 2 * 1024;
+    return a > b ? a : b;
+}
+inline size_t hw_weight_bytes(const TgDisWeights* w) {        // (hi, lo) halves of W_hw as A pieces
+    return (size_t)hw_mb(w->F) * hw_kb(w->F) * 2 * 1024;
+}
+inline int hw_nchunk(const TgDisWeights* w) {                  // partial-logit slots per sequence (either highway kernel)
+    const int a = (w->F + kHwTile - 1) / kHwTile, b = hw_mb(w->F) / 2;   // b: one slot per 64 features
+    return a > b ? a : b;
+}
+
 size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
-    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
-    return align256(sizeof(float) * (size_t)N * w->F) + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut) +
+    return align256(pooled_bytes(w, N)) + align256(sizeof(float) * (size_t)N * hw_nchunk(w) * kMaxOut) +
            align256(sizeof(float) * (size_t)B_prefix * L * w->F) +
            align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256 +
-           align256(2 * sizeof(_Float16) * (size_t)w->F * w->F);
+           align256(hw_weight_bytes(w));
 }
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
 // of all conv banks, the two power-of-two scales, and the (hi, lo) halves of the conv weights.
 // reuse: the workspace still holds the scales and halves an earlier call wrote for the SAME weights and N (the
-// position loop of tg_leak_rollout): only the offsets are recomputed and the pooled |max| slot is cleared.
+// position loop of tg_leak_rollout): only the offsets are recomputed.
 int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, hipStream_t stream, bool reuse) {
-    unsigned* absmax = (unsigned*)scal;          // [0] conv weights, [1] embedding table
+    unsigned* absmax = (unsigned*)scal;          // [0] conv weights, [1] embedding table, [2] W_hw, [3] conv biases
     float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e), -} x 2 (conv, highway)
-    if (hipMemsetAsync(reuse ? absmax + 3 : absmax, 0, reuse ? 4 : 16, stream) != hipSuccess) {
+    if (!reuse && hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
         tg_set_error("hipMemsetAsync failed");
         return TG_ERR_LAUNCH;
     }
@@ -1304,30 +1340,33 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     }
     ca.w16 = w16;
     ca.scales = scales;
-    ca.pooled_absmax = absmax + 3;  // read by the highway's scale (score_impl)
     return TG_OK;
 }
 
-template <int WF, int WS, int NJ>
-int launch_highway_split(HsArgs& hs, hipStream_t stream) {
-    constexpr int TF = 64 * WF, TS = 32 * NJ * WS;
-    constexpr size_t sm = sizeof(_Float16) * 2 * (TF + TS) * kHsStride;
+template <int WM, int WN, int TM, int TN>
+int launch_highway_frag_t(Hw2Args& a, int MBp, int N, hipStream_t stream) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr size_t sm = (size_t)2 * (WM * TM + WN * TN) * 256 * 16;
     static TgLdsAttr attr;
-    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_dis_highway_split<WF, WS, NJ>), sm, "k_dis_highway_split")) return rc;
-    hs.h.nchunk = (hs.h.w.F + TF - 1) / TF;
-    hs.h.nseqtile = (hs.h.N + TS - 1) / TS;
+    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_dis_highway_frag<WM, WN, TM, TN>), sm, "k_dis_highway_frag")) return rc;
+    a.MT = MBp * 32 / BM;
+    a.RT = (N + BN - 1) / BN;
+    a.NB = (a.RT + 7) / 8 * 8 * a.MT;
+    a.h.nchunk = MBp / 2;       // one partial slot per 64 features, whatever the tile shape
+    const int resident = 256 * (int)((160 * 1024) / sm);
+    const int grid = a.NB < resident ? a.NB : resident;
     tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
-    // persistent: as many workgroups as are resident at once (sm bytes of LDS each), a multiple of the 8 XCDs
-    int dev = 0, ncu = 256;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-    const int per_cu = (int)((160 * 1024) / sm) > 0 ? (int)((160 * 1024) / sm) : 1;
-    const long total = (long)hs.h.nseqtile * hs.h.nchunk;
-    long grid = (long)ncu * per_cu;
-    if (grid > total) grid = total;
-    grid = (grid + 7) / 8 * 8;
-    hipLaunchKernelGGL((k_dis_highway_split<WF, WS, NJ>), dim3((unsigned)grid), dim3(64 * WF * WS), sm, stream, hs);
+    hipLaunchKernelGGL((k_dis_highway_frag<WM, WN, TM, TN>), dim3(grid), dim3(64 * WM * WN), sm, stream, a);
     tg_prof_end(stream);
     return TG_OK;
+}
+
+// 256 x 256 tiles (8 waves, 128 KiB LDS, one workgroup per CU) once they fill the chip; 128 x 128 (4 waves, two
+// workgroups per CU) for small launches (the LeakGAN position loop scores 1 280 sequences at a time)
+int launch_highway_frag(Hw2Args& a, int MBp, int N, hipStream_t stream) {
+    const long big = (long)(MBp / 8) * ((N + 255) / 256);
+    if (big >= 256) return launch_highway_frag_t<2, 4, 4, 2>(a, MBp, N, stream);
+    return launch_highway_frag_t<2, 2, 2, 2>(a, MBp, N, stream);
 }
 
 // sentences == nullptr: plain scoring of N arbitrary sequences.
@@ -1356,9 +1395,9 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         return TG_ERR_WORKSPACE;
     }
     float* pooled = (float*)workspace;
-    const int nchunk = (w->F + kHwTile - 1) / kHwTile;
-    float* partial = (float*)((char*)workspace + align256(sizeof(float) * (size_t)N * w->F));
-    float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * nchunk * kMaxOut));
+    const int nchunk = (w->F + kHwTile - 1) / kHwTile;   // fp32 highway; the fragment highway sets its own count
+    float* partial = (float*)((char*)workspace + align256(pooled_bytes(w, N)));
+    float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * hw_nchunk(w) * kMaxOut));
     _Float16* w16 = (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
     void* scal = (char*)w16 + align256(2 * sizeof(_Float16) * conv_weight_count(w));
     _Float16* hw16 = (_Float16*)((char*)scal + 256);
@@ -1374,6 +1413,30 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     } else if (w->precision != TG_DIS_FP32) {
         tg_set_error("tg_dis_score: unknown precision %d", w->precision);
         return TG_ERR_ARG;
+    }
+    // split arithmetic with F % 8 == 0: the pooled features leave the conv as the highway GEMM's B pieces
+    const bool frag = ca.w16 != nullptr && (w->F & 7) == 0 && (size_t)N < ((size_t)1 << 31) - 256;
+    const int KB = hw_kb(w->F), MBp = hw_mb(w->F);
+    if (frag) {
+        unsigned* absmax = (unsigned*)scal;
+        float* scales = (float*)((char*)scal + 16);
+        if (!reuse) {
+            int fmax = 1;
+            for (int k = 0; k < w->n_filters; ++k) fmax = w->f[k] > fmax ? w->f[k] : fmax;
+            const size_t nw = (size_t)w->F * w->F;
+            tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+            hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 512)), dim3(256), 0, stream, w->hw_w,
+                               nw, absmax + 2);
+            hipLaunchKernelGGL(k_absmax_bias, dim3(1), dim3(256), 0, stream, *w, absmax + 3);
+            hipLaunchKernelGGL(k_make_scales_hw, dim3(1), dim3(64), 0, stream, absmax, scales, fmax);
+            hipLaunchKernelGGL(k_hw_make_frag, dim3(1024), dim3(256), 0, stream, w->hw_w, w->F, MBp, KB, scales,
+                               reinterpret_cast<f16x8*>(hw16));
+            hipLaunchKernelGGL(k_pf_zero_pad, dim3(256), dim3(256), 0, stream, reinterpret_cast<f16x8*>(pooled),
+                               (int)hw_rb(N), KB, w->F);
+            tg_prof_end(stream);
+        }
+        ca.pfrag = reinterpret_cast<_Float16*>(pooled);
+        ca.KBp = KB;
     }
     if (sentences) {
         // (1) every window of the B base sentences, (2) running max over time, (3) completions: fresh windows only
@@ -1425,31 +1488,16 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     ha.nchunk = nchunk;
     int nchunk_used = nchunk;
     ha.nseqtile = (N + kHwTile - 1) / kHwTile;
-    if (w->precision == TG_DIS_SPLIT_F16 && (w->F & 7) == 0) {
-        // scales from |max| of hw_w and of the pooled features (the conv kernels' epilogue left that one), then the
-        // (hi, lo) halves of hw_w
-        unsigned* absmax = (unsigned*)scal + 2;
-        float* scales = (float*)((char*)scal + 16) + 4;
-        const size_t nw = (size_t)w->F * w->F;
-        tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
-        if (!reuse)
-            hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 512)), dim3(256), 0, stream, w->hw_w,
-                               nw, absmax);
-        // the pooled features' |max| is this call's own (the conv epilogue left it): the scales are always rebuilt
-        hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
-        if (!reuse)
-            hipLaunchKernelGGL(k_split, dim3(tg_min_host((int)((nw / 4 + 255) / 256) + 1, 2048)), dim3(256), 0, stream,
-                               w->hw_w, nw, hw16, hw16 + nw, scales);
-        tg_prof_end(stream);
-        HsArgs hs = {};
-        hs.h = ha;
-        hs.w_hi = hw16;
-        hs.scales = scales;
-        // 128 x 128 tiles, two workgroups per CU.  (256 x 256 with 512 threads -- <4,2,4> -- halves the operand traffic
-        // but measured 1.7x slower on MI355X: one workgroup per CU, 86 spilled registers, barrier stalls uncovered.)
-        rc = launch_highway_split<2, 2, 2>(hs, stream);
+    if (frag) {
+        Hw2Args h2 = {};
+        h2.h = ha;
+        h2.Wf = reinterpret_cast<const f32x4*>(hw16);
+        h2.Pf = reinterpret_cast<const f32x4*>(pooled);
+        h2.KB = KB;
+        h2.scales = (const float*)((char*)scal + 16);
+        rc = launch_highway_frag(h2, MBp, N, stream);
         if (rc) return rc;
-        nchunk_used = hs.h.nchunk;
+        nchunk_used = h2.h.nchunk;
     } else {
         tg_prof_begin(TG_KERNEL_DIS_HIGHWAY, stream);
         hipLaunchKernelGGL(k_dis_highway, dim3(ha.nseqtile * nchunk), dim3(kHwThreads), 0, stream, ha);
