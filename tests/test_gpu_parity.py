@@ -310,6 +310,32 @@ def test_discriminator_ragged_and_dropout(N, precision):
     np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
 
 
+# filter tables other than the two the reference ships (CNNDiscriminator takes any, models/discriminator.py:20-36):
+# F % 8 != 0 (split mode then runs the exact-fp32 highway), F % 8 == 0 with banks that start off the 4-feature grid
+# (single-feature stores into the highway's B pieces), one bank, more than 8 banks' worth of remainder rows, n_out 8
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
+@pytest.mark.parametrize("fs,ns,n_out,N,L", [((2, 3, 5), (33, 70, 10), 2, 77, 9),
+                                             ((1, 4), (36, 68), 3, 40, 12),
+                                             ((3,), (64,), 8, 300, 7),
+                                             ((1, 2, 3, 4, 5, 6, 7), (5, 9, 13, 17, 21, 25, 30), 2, 33, 8),
+                                             ((2, 7), (250, 6), 5, 513, 11)])
+def test_discriminator_other_filter_tables(fs, ns, n_out, N, L, precision):
+    V = 211
+    sd = synth.dis_state(V, 64, fs, ns, n_out=n_out, seed=21)
+    dis = tg.modules.load_numpy_state(tg.modules.CNNDiscriminator(64, V, list(fs), list(ns), dropout=0.3, n_out=n_out),
+                                      sd, DEV)
+    od = oracle.Dis(sd)
+    seqs = synth.tokens(N + 3, (N, L), V)
+    du = synth.uniform01(N + 4, (N, od.F))
+    col = n_out - 1
+    o = oracle.dis_forward(od, seqs, col=col, dropout_p=0.3, dropout_uniforms=du, want_feature=True)
+    r = tg.ops.dis_score(dis, _t(seqs), col=col, dropout_p=0.3, dropout_uniforms=_t(du), want_logits=True,
+                         want_feature=True, precision=precision)
+    np.testing.assert_allclose(r["feature"].cpu().numpy(), o["feature"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
+
+
 # ------------------------------------------------------------------ get_reward end to end
 @pytest.mark.parametrize("name", _cases.names("get_reward"))
 def test_get_reward(name):

@@ -1,6 +1,11 @@
 """The 2-product scorer (TG_DIS_SPLIT_F16X2) against the exact-fp32 scorer: largest reward / logit difference on the
 reward goldens' completions, on the weight-scale cases of test_scorer_split_precision_across_weight_scales, and on a
-discriminator scaled to O(1) logits (what a trained D produces); the 3-product default beside it."""
+discriminator scaled to O(1) logits (what a trained D produces); the 3-product default beside it.
+
+Historical: the "split_f16x2" precision this probe selects was an experimental build that failed the acceptance rule and
+is NOT in the library (profiles/r02_x2_scorer_probe.txt holds its output); against the
+current library the probe stops at the first split_f16x2 call with "unknown precision".  Kept as the record of how the
+numbers were produced."""
 import sys, os, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
