@@ -78,7 +78,7 @@ struct ConvArgs {
     uint8_t mfmax[kMaxMerged], mfmin[kMaxMerged];
     const MergedMeta* mmeta;   // [n_merged]
     ConvItem items[kMaxItems]; // sorted by cost, heaviest first
-    long long* stamps;         // diagnostic (TG_CONV_STAMPS env = device pointer): per workgroup [16] clock64 values
+    long long* stamps;         // diagnostic (TG_CONV_STAMPS env = device pointer): per wave [8] values (8 waves per workgroup)
 };
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -98,8 +98,10 @@ __device__ __forceinline__ void pf_store4(_Float16* pf, int KB, int seq, int f, 
         h[e] = (_Float16)x;
         l[e] = (_Float16)(x - (float)h[e]);
     }
-    const size_t piece = (((size_t)(seq >> 5) * KB + (f >> 4)) * 2) * 64 + (seq & 31) + 32 * ((f >> 3) & 1);
-    f16x4* d = reinterpret_cast<f16x4*>(pf + piece * 8) + ((f >> 2) & 1);
+    // (sequence block, k block) fits 32 bits: the piece array (2 KiB per block) is a workspace in HBM
+    const unsigned blk = (unsigned)(seq >> 5) * (unsigned)KB + (unsigned)(f >> 4);
+    const unsigned in_blk = (unsigned)(seq & 31) + 32u * ((f >> 3) & 1);
+    f16x4* d = reinterpret_cast<f16x4*>(pf + ((size_t)blk << 10) + in_blk * 8) + ((f >> 2) & 1);
     d[0] = h;
     d[128] = l;  // the lo piece: 64 pieces = 128 f16x4 further
 }
@@ -110,6 +112,31 @@ __device__ __forceinline__ void pf_store1(_Float16* pf, int KB, int seq, int f, 
     _Float16* d = pf + piece * 8 + (f & 7);
     d[0] = h;
     d[512] = (_Float16)(x - (float)h);
+}
+
+// Max over the lanes n, n+S, n+2S, ... of each 32-lane half (S a power of two), left in every one of them, on the VALU
+// alone: rotations inside the 16-lane rows (DPP row_ror) and, for the two rows of a half, v_permlane16_swap of the
+// register with itself (one result holds row 0 | row 0 | row 2 | row 2, the other row 1 | row 1 | row 3 | row 3).
+// __shfl_xor would go through the LDS crossbar, which the partner wave's operand reads are using.
+template <int CTRL>
+__device__ __forceinline__ void row_ror_max16(float (&x)[16]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        x[r] = __builtin_fmaxf(x[r], __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(x[r]), CTRL, 0xf, 0xf, false)));
+}
+__device__ __forceinline__ void group_max16(float (&x)[16], int S) {
+    if (S <= 1) row_ror_max16<0x121>(x);
+    if (S <= 2) row_ror_max16<0x122>(x);
+    if (S <= 4) row_ror_max16<0x124>(x);
+    if (S <= 8) row_ror_max16<0x128>(x);
+    if (S <= 16) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned u = __float_as_uint(x[r]);
+            const auto sw = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+            x[r] = __builtin_fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        }
+    }
 }
 
 // SPLIT = false: exact fp32 on v_mfma_f32_32x32x2_f32.
@@ -196,16 +223,19 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         g_min = __builtin_amdgcn_readfirstlane(g_min);
     }
 
+    const float sP = (SPLIT && a.pfrag) ? a.scales[5] : 1.f;   // scale of the pooled features' (hi, lo) halves
     const long long st1 = tg_clock();
-    long long st_mfma = 0;
+    long long st_mfma = 0, st_fetch = 0, st_epi = 0;
     int st_items = 0;
     for (;;) {
+        const long long st_top = a.stamps ? tg_clock() : 0;
         int item = 0;
         if (lane == 0) item = atomicAdd(ctr, 1);
         // gridDim.y > 1 (few sequences: the sentence pass): the items are dealt round-robin to the y workgroups
         item = __builtin_amdgcn_readfirstlane(item) * (int)gridDim.y + (int)blockIdx.y;
         if (item >= a.n_items) break;
         const long long st_item = tg_clock();
+        if (a.stamps) st_fetch += st_item - st_top;
         const int k = a.items[item].k, mt = a.items[item].mt;
         const bool merged = SPLIT && k == 0xFF;  // mt = merged tile index
         const int f = merged ? a.mfmax[mt] : a.w.f[k];
@@ -366,13 +396,67 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 finish_chunk(nb0, nbc);
             }
         }
-        if (a.stamps) { st_mfma += tg_clock() - st_item; ++st_items; }
+        const long long st_mend = a.stamps ? tg_clock() : 0;
+        if (a.stamps) { st_mfma += st_mend - st_item; ++st_items; }
         if (MODE == kConvStoreAll) continue;
-        // combine the TT time sub-positions of a sequence (lanes n, n+S, n+2S, ...)
-        for (int off = S; off < 32; off <<= 1) {
+        // Plain banks: after the butterfly below every lane of a sequence holds all 16 maxima, so its TT lanes split the
+        // four 4-filter quads between them (D reg r -> filter mt*32 + (r&3) + 8*(r>>2) + 4*hh; lane tsub takes quads
+        // tsub, tsub + nq, ...): one pass of the store body per wave instead of four on a quarter of the lanes, and
+        // its loads (bias, prefix maxima) are issued before the butterfly.  (Tried: issuing them during the item's last
+        // MFMA stage into the idle weight-fragment registers -- the epilogue shrank by 15 % but the stage loop grew by
+        // 8 %, spills; not kept.)
+        const int nq = TT < 4 ? TT : 4;
+        const bool act = !merged && tsub < nq && seq0 + s < a.N;
+        const int fo = merged ? 0 : a.foff[k];
+        const float* pb = merged ? nullptr : a.w.conv_b[k];
+        // Prefix mode: max over the windows t <= g - f (bias included) of the base sentence
+        const float* pm = (!merged && MODE == kConvPrefix && g_lane >= f)
+                              ? a.cv + ((size_t)b_lane * L + (g_lane - f)) * a.w.F + fo : nullptr;
+        const bool aligned = ((fo | a.w.F) & 3) == 0 && (reinterpret_cast<uintptr_t>(pb) & 15) == 0;
+        auto quad_vec = [&](int rq) __attribute__((always_inline)) {   // this lane's quad rq goes the 16-byte way
+            return act && aligned && mt * 32 + 8 * rq + 4 * hh + 4 <= nk;
+        };
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f}, pv = {0.f, 0.f, 0.f, 0.f};
+        auto load_quad = [&](int rq, f32x4& b4, f32x4& p4) __attribute__((always_inline)) {
+            const int m0 = mt * 32 + 8 * rq + 4 * hh;
+            if (quad_vec(rq)) {
+                b4 = *reinterpret_cast<const f32x4*>(pb + m0);
+                if (pm) p4 = *reinterpret_cast<const f32x4*>(pm + m0);
+            }
+        };
+        auto finish_quad = [&](int rq, bool vq) __attribute__((always_inline)) {
+            const int m0 = mt * 32 + 8 * rq + 4 * hh;
+            float v[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) runmax[r] = __builtin_fmaxf(runmax[r], __shfl_xor(runmax[r], off, 64));
-        }
+            for (int e = 0; e < 4; ++e) {   // two-level select on the bits of rq (a chain of == tests becomes an indexed
+                                           // load and sends runmax to scratch memory)
+                const float lo2 = (rq & 1) ? runmax[4 + e] : runmax[e], hi2 = (rq & 1) ? runmax[12 + e] : runmax[8 + e];
+                v[e] = (rq & 2) ? hi2 : lo2;
+            }
+            if (vq) {
+                float o4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o4[e] = __builtin_fmaxf(v[e] + bv[e], 0.f);
+                    if (pm) o4[e] = __builtin_fmaxf(o4[e], pv[e]);
+                }
+                if (SPLIT && a.pfrag) pf_store4(a.pfrag, a.KBp, seq0 + s, fo + m0, o4, sP);
+                else *reinterpret_cast<f32x4*>(a.pooled + (size_t)(seq0 + s) * a.w.F + fo + m0) = f32x4{o4[0], o4[1], o4[2], o4[3]};
+            } else if (act) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (m0 + e < nk) {
+                        float o = __builtin_fmaxf(v[e] + pb[m0 + e], 0.f);
+                        if (pm) o = __builtin_fmaxf(o, pm[m0 + e]);
+                        if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, fo + m0 + e, o, sP);
+                        else a.pooled[(size_t)(seq0 + s) * a.w.F + fo + m0 + e] = o;
+                    }
+            }
+        };
+        const bool vq0 = quad_vec(tsub & 3);
+        if (!merged) load_quad(tsub & 3, bv, pv);
+        // combine the TT time sub-positions of a sequence (lanes n, n+S, n+2S, ...)
+        group_max16(runmax, S);
         if (merged) {
             if (tsub == 0 && seq0 + s < a.N) {
                 float* po = a.pooled + (size_t)(seq0 + s) * a.w.F;
@@ -383,54 +467,24 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                     float o = __builtin_fmaxf(runmax[r] + mm->bias[mrow(r)], 0.f);
                     if (MODE == kConvPrefix && g_lane >= fwr)
                         o = __builtin_fmaxf(o, a.cv[((size_t)b_lane * L + (g_lane - fwr)) * a.w.F + ft]);
-                    if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, ft, o, a.scales[5]);
+                    if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, ft, o, sP);
                     else po[ft] = o;
                 }
             }
+            if (a.stamps) st_epi += tg_clock() - st_mend;
             continue;
         }
-        // bias + ReLU, store: D reg r -> filter mt*32 + (r&3) + 8*(r>>2) + 4*hh
-        if (tsub == 0 && seq0 + s < a.N) {
-            float* po = a.pooled + (size_t)(seq0 + s) * a.w.F + a.foff[k];
-            const float* pb = a.w.conv_b[k];
-            // Prefix mode: max over the windows t <= g - f (bias included) of the base sentence
-            const float* pm = (MODE == kConvPrefix && g_lane >= f)
-                                  ? a.cv + ((size_t)b_lane * L + (g_lane - f)) * a.w.F + a.foff[k] : nullptr;
-#pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int m0 = mt * 32 + 8 * rq + 4 * hh;
-                if (m0 + 4 <= nk && (((a.foff[k] + m0) | a.w.F) & 3) == 0) {
-                    f32x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
-                    if (pm) {
-                        const f32x4 pv = *reinterpret_cast<const f32x4*>(pm + m0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = __builtin_fmaxf(o[e], pv[e]);
-                    }
-                    if (SPLIT && a.pfrag) {
-                        const float o4[4] = {o[0], o[1], o[2], o[3]};
-                        pf_store4(a.pfrag, a.KBp, seq0 + s, a.foff[k] + m0, o4, a.scales[5]);
-                    } else {
-                        *reinterpret_cast<f32x4*>(po + m0) = o;
-                    }
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (m0 + e < nk) {
-                            float o = __builtin_fmaxf(runmax[4 * rq + e] + pb[m0 + e], 0.f);
-                            if (pm) o = __builtin_fmaxf(o, pm[m0 + e]);
-                            if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, a.foff[k] + m0 + e, o, a.scales[5]);
-                            else po[m0 + e] = o;
-                                }
-                }
-            }
+        finish_quad(tsub & 3, vq0);
+        for (int j = nq; j < 4; j += nq) {   // TT < 4: the lane's further quads
+            load_quad((tsub & 3) + j, bv, pv);
+            finish_quad((tsub & 3) + j, quad_vec((tsub & 3) + j));
         }
+        if (a.stamps) st_epi += tg_clock() - st_mend;
     }
     if (a.stamps && lane == 0) {
         const long long st2 = tg_clock();
-        long long* o = a.stamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 4;
-        o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st_mfma; o[3] = st_items;
+        long long* o = a.stamps + ((size_t)blockIdx.x * 8 + (tid >> 6)) * 8;
+        o[0] = st1 - st0; o[1] = st2 - st1; o[2] = st_mfma; o[3] = st_items; o[4] = st_fetch; o[5] = st_epi;
     }
 }
 

@@ -11,17 +11,19 @@ u = torch.rand(R, L, L, B, device=dev)
 comp = tg.ops.gen_rollout(gen, sent, R, u)
 tg.ops.dis_score_rollout(dis, sent, comp)
 nwg = R * L * B // 8
-st = torch.zeros(nwg * 8 * 4 + 1024, dtype=torch.int64, device=dev)
+st = torch.zeros(nwg * 8 * 8 + 1024, dtype=torch.int64, device=dev)
 os.environ["TG_CONV_STAMPS"] = str(st.data_ptr())
 tg.ops.dis_score_rollout(dis, sent, comp); torch.cuda.synchronize()
 del os.environ["TG_CONV_STAMPS"]
-s = st[:nwg * 32].cpu().numpy().astype(np.float64).reshape(nwg, 8, 4)
+s = st[:nwg * 64].cpu().numpy().astype(np.float64).reshape(nwg, 8, 8)
 gather, loop, mfma, items = s[..., 0], s[..., 1], s[..., 2], s[..., 3]
 wg_total = (gather + loop).max(1)
 print("workgroups", nwg, "mean WG cycles %.0f" % wg_total.mean())
 print("gather  mean %.0f (%.1f%% of WG)" % (gather.mean(), 100 * gather.mean() / wg_total.mean()))
 print("item loop per wave mean %.0f, in-item (MFMA stages + chunk epilogues) %.0f (%.1f%% of WG), items/wave %.1f"
       % (loop.mean(), mfma.mean(), 100 * mfma.mean() / wg_total.mean(), items.mean()))
+print("item fetch (counter, descriptor) per wave mean %.0f (%.1f%%), item epilogue %.0f (%.1f%%)"
+      % (s[..., 4].mean(), 100 * s[..., 4].mean() / wg_total.mean(), s[..., 5].mean(), 100 * s[..., 5].mean() / wg_total.mean()))
 print("wave idle at the end of the WG: mean %.0f (%.1f%%)" % ((wg_total[:, None] - gather - loop).mean(),
       100 * (wg_total[:, None] - gather - loop).mean() / wg_total.mean()))
 g = (np.arange(nwg) * 8 // B) % L + 1
