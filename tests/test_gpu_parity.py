@@ -310,6 +310,25 @@ def test_discriminator_ragged_and_dropout(N, precision):
     np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
 
 
+def test_discriminator_unaligned_dropout_uniforms():
+    """dropout uniforms that start 4 bytes into an allocation (a contiguous view): the 16-byte epilogue loads of the
+    split highway cannot be used; the call must still match the oracle."""
+    V, L, N = 97, 23, 70
+    sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=9)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), sd, DEV)
+    od = oracle.Dis(sd)
+    seqs = synth.tokens(N, (N, L), V)
+    du = synth.uniform01(N + 1, (N, od.F))
+    o = oracle.dis_forward(od, seqs, col=1, dropout_p=0.25, dropout_uniforms=du)
+    buf = torch.empty(N * od.F + 1, device=DEV)
+    view = buf[1:].view(N, od.F)
+    view.copy_(_t(du))
+    assert view.is_contiguous() and view.data_ptr() % 16 == 4
+    r = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=0.25, dropout_uniforms=view, want_logits=True)
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
+
+
 # filter tables other than the two the reference ships (CNNDiscriminator takes any, models/discriminator.py:20-36):
 # F % 8 != 0 (split mode then runs the exact-fp32 highway), F % 8 == 0 with banks that start off the 4-feature grid
 # (single-feature stores into the highway's B pieces), one bank, more than 8 banks' worth of remainder rows, n_out 8

@@ -1469,7 +1469,11 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         return TG_ERR_ARG;
     }
     // split arithmetic with F % 8 == 0: the pooled features leave the conv as the highway GEMM's B pieces
-    const bool frag = ca.w16 != nullptr && (w->F & 7) == 0 && (size_t)N < ((size_t)1 << 31) - 256;
+    // (its epilogue reads the highway bias, the output layer, the dropout uniforms and writes the features 16 bytes at
+    // a time: tensors that are not 16-byte aligned -- views into a larger buffer -- take the exact-fp32 highway too)
+    const uintptr_t al16 = reinterpret_cast<uintptr_t>(w->hw_b) | reinterpret_cast<uintptr_t>(w->out_w) |
+                           reinterpret_cast<uintptr_t>(dropout_uniforms) | reinterpret_cast<uintptr_t>(feature_out);
+    const bool frag = ca.w16 != nullptr && (w->F & 7) == 0 && (al16 & 15) == 0 && (size_t)N < ((size_t)1 << 31) - 256;
     const int KB = hw_kb(w->F), MBp = hw_mb(w->F);
     if (frag) {
         unsigned* absmax = (unsigned*)scal;
