@@ -34,6 +34,12 @@ extern "C" {
 #define TG_ERR_LAUNCH (-2)   /* HIP launch or runtime error                 */
 #define TG_ERR_WORKSPACE (-3)/* workspace too small                         */
 
+/* Alignment.  Weight tensors (every pointer in TgGenWeights / TgLeakWeights; the embedding, conv and highway
+ * matrices of TgDisWeights) must be 16-byte aligned -- torch parameters are (own allocations, 256-byte aligned);
+ * a misaligned one is rejected with TG_ERR_ARG.  Workspaces must be 256-byte aligned.  Token, uniform and output
+ * arrays need only their natural alignment (the scorer takes a slower exact-fp32 highway when its bias, output layer,
+ * dropout uniforms or feature output are not 16-byte aligned). */
+
 /* LSTMGenerator parameters: models/generator.py:33-35 (state_dict keys
  * embeddings.weight, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0,
  * lstm.bias_hh_l0, lstm2out.weight, lstm2out.bias).  Gate order i,f,g,o. */

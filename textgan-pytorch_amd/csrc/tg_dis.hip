@@ -1173,6 +1173,14 @@ int check_dis(const TgDisWeights* w, int L) {
         tg_set_error("discriminator: feature dim %d != sum of filters %d", w->F, F);
         return TG_ERR_ARG;
     }
+    // the kernels read the matrices 16 bytes at a time (include/textgan_hip.h, "Alignment")
+    uintptr_t al = reinterpret_cast<uintptr_t>(w->emb) | reinterpret_cast<uintptr_t>(w->hw_w);
+    for (int k = 0; k < w->n_filters; ++k) al |= reinterpret_cast<uintptr_t>(w->conv_w[k]);
+    if ((al & 15) || ((reinterpret_cast<uintptr_t>(w->hw_b) | reinterpret_cast<uintptr_t>(w->out_w) |
+                       reinterpret_cast<uintptr_t>(w->out_b)) & 3)) {
+        tg_set_error("discriminator weights: embeddings, conv and highway matrices must be 16-byte aligned");
+        return TG_ERR_ARG;
+    }
     return TG_OK;
 }
 

@@ -985,6 +985,13 @@ int check_weights(const TgGenWeights* w, bool wide_ok = false) {
         tg_set_error("generator weights: null pointer");
         return TG_ERR_ARG;
     }
+    // the kernels read the matrices 16 bytes at a time (include/textgan_hip.h, "Alignment")
+    if ((reinterpret_cast<uintptr_t>(w->emb) | reinterpret_cast<uintptr_t>(w->w_ih) | reinterpret_cast<uintptr_t>(w->w_hh) |
+         reinterpret_cast<uintptr_t>(w->w_out) | reinterpret_cast<uintptr_t>(w->b_ih) | reinterpret_cast<uintptr_t>(w->b_hh) |
+         reinterpret_cast<uintptr_t>(w->b_out)) & 15) {
+        tg_set_error("generator weights: every tensor must be 16-byte aligned");
+        return TG_ERR_ARG;
+    }
     const int sup = tg_gen_supported(w->V, w->E, w->H);
     if (sup == 0 || (sup == 1 && wide_ok && tg_genw_applies(w))) return TG_OK;
     if (sup == 1)

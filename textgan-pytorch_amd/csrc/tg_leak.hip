@@ -514,6 +514,16 @@ int check_leak(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, int 
         tg_set_error("tg_leak_rollout: null weight pointer");
         return TG_ERR_ARG;
     }
+    {
+        const void* ptrs[] = {g->emb, g->w_wih, g->w_whh, g->w_bih, g->w_bhh, g->m_wih, g->m_whh, g->m_bih, g->m_bhh,
+                              g->w2g_w, g->w2g_b, g->m2g_w, g->m2g_b, g->g2g_w, g->goal_init};
+        uintptr_t al = 0;
+        for (const void* q : ptrs) al |= reinterpret_cast<uintptr_t>(q);
+        if (al & 15) {   // include/textgan_hip.h, "Alignment"
+            tg_set_error("tg_leak_rollout: every weight tensor must be 16-byte aligned");
+            return TG_ERR_ARG;
+        }
+    }
     if (g->H % 32 || g->H < 32 || g->H > kMaxHLeak || g->E < 1 || g->K < 1 || g->K > 64 || g->V < 1 || g->V > 32768 ||
         g->step_size < 1) {
         tg_set_error("tg_leak_rollout: shape V=%d E=%d H=%d K=%d step=%d not supported (H a multiple of 32 up to %d, "
