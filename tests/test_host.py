@@ -38,6 +38,23 @@ def test_no_cpu_fallback():
         tg.ops.gen_sample(gen, 4, 20, 1, torch.rand(20, 4))
 
 
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under the product package (Python or HIP sources, the Makefile)
+    imports, loads, links or names it, nor the reference checkout."""
+    pkg = os.path.dirname(os.path.abspath(tg._lib.__file__))
+    bad = re.compile(r"\boracle\s*(import|\.|/)|import\s+oracle|from\s+oracle|libtextgan_oracle|/root/reference")
+    hits = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp", ".c")) or f == "Makefile":
+                for i, line in enumerate(open(os.path.join(d, f), errors="replace"), 1):
+                    # "oracle" also names the reference's Oracle generator (models/Oracle.py) and its data set
+                    code = line.split("#")[0] if f.endswith(".py") else line.split("//")[0]   # comments may cite it
+                    if bad.search(code):
+                        hits.append("%s:%d: %s" % (os.path.join(d, f), i, line.strip()))
+    assert not hits, "\n".join(hits)
+
+
 def test_rollout_attributes_mirror_reference():
     gen = tg.modules.synthetic_generator(50, 32, 32, 20, device="cpu")
     ro = tg.ROLLOUT(gen, gpu=True)
