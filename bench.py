@@ -159,7 +159,7 @@ def bench_nll(args, dev):
                                "sample": "first %d sequences (%.1f s)" % (ns, t)}
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    return out
 
 
 def bench_pg(args, dev):
@@ -239,7 +239,7 @@ def bench_pg(args, dev):
                                          "threads for the matrix products)" % t}
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    return out
 
 
 def bench_leak(args, dev):
@@ -312,7 +312,7 @@ def bench_leak(args, dev):
                                "sample": "same workload at rollout_num 1 (%d completions, %.1f s)" % (T * B, t)}
     else:
         out["cpu_baseline"] = None
-    print(json.dumps(out))
+    return out
 
 
 def run_rollout(args, name, world, rank, dev, steps, warmup):
@@ -373,7 +373,7 @@ def run_rollout(args, name, world, rank, dev, steps, warmup):
     prof = tg._lib.profile_read()
     tg._lib.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert tuple(rewards.shape) == (B, L) and bool(torch.isfinite(rewards).all())
@@ -470,30 +470,47 @@ def main():
                     help="generator vocabulary-projection arithmetic (default: the library default, split_f16)")
     args = ap.parse_args()
 
+    # stdout carries the one JSON line and nothing else: whatever libraries print there (gloo's connection banner,
+    # RCCL or MIOpen notices) goes to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(record):
+        os.write(json_fd, (json.dumps(record) + "\n").encode())
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
                          % (args.gpus, world, args.gpus))
+    # TG_BENCH_REHEARSE=1: every rank on GPU 0 over gloo -- a rehearsal of the N > 1 code path on a one-GPU box (RCCL
+    # refuses two ranks on one device); the numbers of such a run mean nothing
+    rehearse = os.environ.get("TG_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     if args.workload == "c5":
         if world > 1:
             raise SystemExit("workload c5 (NLL) is a single-GPU side measurement")
-        return bench_nll(args, dev)
+        return emit(bench_nll(args, dev))
     if args.workload == "pg":
         if world > 1:
             raise SystemExit("workload pg (policy-gradient step) is a single-GPU side measurement")
-        return bench_pg(args, dev)
+        return emit(bench_pg(args, dev))
     if args.workload == "leak":
         if world > 1:
             raise SystemExit("workload leak (LeakGAN rollout) is a single-GPU side measurement")
-        return bench_leak(args, dev)
+        return emit(bench_leak(args, dev))
     if args.workload != "default":
         out = run_rollout(args, args.workload, world, rank, dev, args.steps, args.warmup)
     else:
@@ -508,7 +525,7 @@ def main():
             if rank == 0:
                 out["scaled"] = sub
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
