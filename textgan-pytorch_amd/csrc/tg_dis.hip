@@ -1423,11 +1423,15 @@ int launch_highway_frag_t(Hw2Args& a, int MBp, int N, hipStream_t stream) {
     return TG_OK;
 }
 
-// 256 x 256 tiles (8 waves, 128 KiB LDS, one workgroup per CU) once they fill the chip; 128 x 128 (4 waves, two
-// workgroups per CU) for small launches (the LeakGAN position loop scores 1 280 sequences at a time)
+// 256 x 256 tiles (8 waves, 128 KiB LDS, one workgroup per CU) or 128 x 128 (4 waves, two workgroups per CU): whichever
+// needs fewer passes over the chip.  In units of one 128 x 128 tile on a CU of its own: a big tile costs 4 x 0.93 (it
+// moves half the operand bytes per flop), a small one 2 (its CU is shared); the chip holds 256 big or 512 small
+// workgroups per pass.  C2 (52 224 sequences) takes the big tiles, the LeakGAN position loop (1 280) and SentiGAN's
+// F = 800 scorer the small ones.
 int launch_highway_frag(Hw2Args& a, int MBp, int N, hipStream_t stream) {
-    const long big = (long)(MBp / 8) * ((N + 255) / 256);
-    if (big >= 256) return launch_highway_frag_t<2, 4, 4, 2>(a, MBp, N, stream);
+    const long big = (long)(MBp / 8) * ((N + 255) / 256), small = (long)(MBp / 4) * ((N + 127) / 128);
+    const double cost_big = (double)((big + 255) / 256) * 4.0 * 0.93, cost_small = (double)((small + 511) / 512) * 2.0;
+    if (cost_big <= cost_small) return launch_highway_frag_t<2, 4, 4, 2>(a, MBp, N, stream);
     return launch_highway_frag_t<2, 2, 2, 2>(a, MBp, N, stream);
 }
 
