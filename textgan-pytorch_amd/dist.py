@@ -133,11 +133,14 @@ def sync_weights(gen, dis=None, group=WORLD, src=0):
             else:
                 dist.broadcast(flat, src=root, group=g)
             nbytes += flat.numel() * flat.element_size()
-            off = 0
+            if dist.get_rank(g) == src:
+                continue                       # the source's own tensors already hold these values
+            views, off = [], 0
             for t in ts:
                 n = t.numel()
-                t.detach().copy_(flat[off:off + n].view_as(t))
+                views.append(flat[off:off + n].view_as(t))
                 off += n
+            torch._foreach_copy_([t.detach() for t in ts], views)   # one fused scatter back, not a launch per tensor
     return nbytes
 
 
