@@ -157,7 +157,23 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
     const int lane = tid & 63;
     const int n = lane & 31;
     const int hh = lane >> 5;
-    const int seq0 = blockIdx.x * S;
+    // Workgroup -> sequence group.  Prefix mode with 8 | B/S: workgroup ids are dealt round-robin to the 8 XCDs, so XCD x
+    // walks the groups (g, sentence block x + 8 j, rollout index i) with i innermost -- the R workgroups that read the
+    // same rows of the prefix table (and gather the same prefix embeddings) run back to back in one L2 -- and g ascending,
+    // i.e. the workgroups with the most fresh windows first.  The order changes nothing in the results.
+    int grp = blockIdx.x;
+    if (MODE == kConvPrefix && gridDim.y == 1) {
+        const int nb = a.B >> log2S;              // sentence blocks per (i, g)
+        const int RLnb = (int)gridDim.x;          // = R * L * nb when the remap applies
+        if ((nb << log2S) == a.B && (nb & 7) == 0 && RLnb % (L * nb) == 0 && (size_t)RLnb * S == (size_t)a.N) {
+            const int R = RLnb / (L * nb), x = grp & 7;
+            int slot = grp >> 3;                  // this XCD's slot: (g, j, i), i fastest
+            const int i = slot % R; slot /= R;
+            const int j = slot % (nb >> 3), g = slot / (nb >> 3);
+            grp = (i * L + g) * nb + x + 8 * j;
+        }
+    }
+    const int seq0 = grp * S;
 
     // ---- gather: token embeddings -> LDS, time-major [t][s][68].  Eight 16-B pieces per thread and pass, all token
     // reads first and all embedding reads next: two memory round trips per pass instead of two per piece.
