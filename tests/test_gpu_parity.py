@@ -726,6 +726,46 @@ def test_leak_reward_c1_shape_full_vs_oracle():
         assert torch.equal(comp[:, t, :, :given[t]], _t(sent)[:, :given[t]].expand(R, B, given[t]))
 
 
+def test_concurrent_calls_on_two_streams():
+    """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
+    its own, run get_reward with different uniforms at the same time, several times over; each result must equal the
+    same call made alone."""
+    import threading
+    c = _cases.load("reward_tiny_dropout")
+    gen, dis = _gen(c), _dis(c)
+    sent, u, du = _cases.reward_inputs(c)
+    R, col, p = int(c["R"]), int(c["current_k"]), float(c["dropout_p"])
+    us = [_t(u), _t(synth.uniform01(991, u.shape))]
+    dus = [_t(du), _t(synth.uniform01(992, du.shape))]
+    sent_t = _t(sent)
+    alone = [tg.ROLLOUT(gen).get_reward(sent_t, R, dis, col, uniforms=us[k], dropout_uniforms=dus[k]).clone() for k in (0, 1)]
+    torch.cuda.synchronize()
+    outs, errs = [[], []], []
+
+    def work(k):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                ro = tg.ROLLOUT(gen)
+                for _ in range(8):
+                    outs[k].append(ro.get_reward(sent_t, R, dis, col, uniforms=us[k], dropout_uniforms=dus[k]))
+            st.synchronize()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for k in (0, 1):
+        assert len(outs[k]) == 8
+        for r in outs[k]:
+            assert torch.equal(r, alone[k])
+    assert not torch.equal(alone[0], alone[1])
+
+
 def test_errors_and_cpu_inputs():
     gen = tg.modules.synthetic_generator(100, 32, 32, 20, device=DEV)
     with pytest.raises(RuntimeError):
