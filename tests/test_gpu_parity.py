@@ -454,6 +454,31 @@ def test_get_reward_c1_full_vs_oracle(precision):
     assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
 
 
+def test_get_reward_c4_full_vs_oracle():
+    """BASELINE config 4 at full size for one of its k = 4 generators (V5000 L20 E=H=32 B64 R16, SentiGAN's 5-way
+    scorer F = 800 with live dropout p = 0.2, column current_k + 1 = 3): 20 480 completions against the oracle."""
+    V, L, B, R, cur_k = 5000, 20, 64, 16, 2
+    gsd = synth.gen_state(V, 32, 32, seed=cur_k, std=1.0)
+    dsd = synth.dis_state(V, 64, *synth.SENTIGAN_D_FILTERS, n_out=5, seed=0)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SentiGAN_D(4, 64, V), dsd, DEV)
+    assert dis.training and dis.dropout.p == 0.2
+    sent = synth.tokens(1, (B, L), V)
+    u = synth.uniform01(2, (R, L, L, B))
+    og, od = oracle.Gen(gsd), oracle.Dis(dsd)
+    du = synth.uniform01(3, (R * L, B, od.F))
+    o = oracle.get_reward(og, od, sent, R, u, col=cur_k + 1, dropout_p=0.2, dropout_uniforms=du)
+    rew, raw, comp = tg.ROLLOUT(gen).get_reward(_t(sent), R, dis, cur_k, uniforms=_t(u), dropout_uniforms=_t(du),
+                                                return_parts=True)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
+    assert same.mean() >= 0.98
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, L, R).all(-1)
+    assert ok.mean() >= 0.9
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
+    assert np.all((raw.cpu().numpy() >= 0) & (raw.cpu().numpy() <= 1))
+
+
 @pytest.mark.parametrize("std,bias_scale", [(0.01, 1.0), (4.0, 1.0), (1.0, 50.0), (1e-4, 1e-3)])
 def test_generator_split_precision_across_weight_scales(std, bias_scale):
     """The split projection scales its operands by a power of two taken from |max|: token parity with the oracle has
