@@ -26,7 +26,9 @@ print("item fetch (counter, descriptor) per wave mean %.0f (%.1f%%), item epilog
       % (s[..., 4].mean(), 100 * s[..., 4].mean() / wg_total.mean(), s[..., 5].mean(), 100 * s[..., 5].mean() / wg_total.mean()))
 print("wave idle at the end of the WG: mean %.0f (%.1f%%)" % ((wg_total[:, None] - gather - loop).mean(),
       100 * (wg_total[:, None] - gather - loop).mean() / wg_total.mean()))
-g = (np.arange(nwg) * 8 // B) % L + 1
+# workgroup id -> given_num under the per-XCD order of k_dis_conv<Prefix> (8 | B/S): slot = id >> 3 = (g, j, i), i fastest
+nb = B // 8
+g = (np.arange(nwg) >> 3) // (R * (nb // 8)) + 1
 for lo, hi in ((1, 5), (20, 30), (45, 50)):
     m = (g >= lo) & (g <= hi)
     print("g in [%d,%d]: WG cycles %.0f gather %.0f in-item %.0f" % (lo, hi, wg_total[m].mean(), gather[m].mean(), mfma[m].mean()))
