@@ -147,6 +147,35 @@ def test_rollout_subranges_and_mc_search():
     assert torch.equal(full[:, L - 1], _t(sent).expand(R, B, L))  # given_num == L is the sentence itself
 
 
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+@pytest.mark.parametrize("V,B,L,R", [(2, 1, 20, 1), (3, 1, 21, 2), (17, 2, 20, 3), (129, 33, 20, 1), (16, 7, 25, 5),
+                                     (5255, 3, 51, 1)])
+def test_get_reward_edge_shapes_against_oracle(V, B, L, R, precision):
+    """The smallest and most ragged calls get_reward accepts at E = H = 32: a two-word vocabulary (one sampler tile,
+    mostly padding), a single sentence, a single rollout, batches that are not a multiple of anything, L just over the
+    widest filter.  Step-wise token parity and rewards against the oracle."""
+    gsd = synth.gen_state(V, 32, 32, seed=V + B, std=1.0)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=5)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), dsd, DEV)
+    og, od = oracle.Gen(gsd), oracle.Dis(dsd)
+    sent, u = synth.tokens(31, (B, L), V), synth.uniform01(32, (R, L, L, B))
+    du = synth.uniform01(33, (R * L, B, od.F))
+    o = oracle.get_reward(og, od, sent, R, u, dropout_p=0.25, dropout_uniforms=du)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"]), precision=precision).cpu().numpy()
+    _cases.check_token_parity(replay, o["completions"], u, og)
+    ro = tg.ROLLOUT(gen)
+    ro.gen_precision = precision
+    rew, raw, comp = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), dropout_uniforms=_t(du), return_parts=True)
+    assert tuple(rew.shape) == (B, L) and tuple(raw.shape) == (R * L, B)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    if same.all():
+        np.testing.assert_allclose(rew.cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
+    # given_num == L scores the sentence itself, whatever the uniforms
+    assert torch.equal(comp[:, L - 1], _t(sent).expand(R, B, L))
+
+
 # ------------------------------------------------------------------ generator beyond E = H = 32 (tg_genw.hip)
 WIDE_CASES = [
     # V, E, H, B, L, R, std -- the canonical sampler has more than 16 groups per span above V = 16384, B*R*L and V
