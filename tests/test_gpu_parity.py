@@ -883,6 +883,25 @@ def test_pg_loss_c2_shape_against_oracle():
     assert loss2.item() < loss.item()  # one Adam step on the same batch lowers the loss
 
 
+@pytest.mark.parametrize("V,E,H,B,L", [(2, 32, 32, 1, 2), (5, 32, 32, 33, 7), (129, 32, 32, 2, 20), (7, 64, 96, 1, 3),
+                                       (33, 96, 32, 35, 4)])
+def test_pg_loss_edge_shapes_against_oracle(V, E, H, B, L):
+    """The policy-gradient loss and all seven gradients on the smallest and most ragged batches (one sentence of two
+    tokens, a two-word vocabulary, row counts off every tile size), fused kernels (E = H = 32) and GEMM path alike."""
+    sd = synth.gen_state(V, E, H, seed=V + L, std=0.3)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L, name="seqgan"), sd, DEV)
+    target = synth.tokens(41, (B, L), V)
+    inp = np.concatenate([np.zeros((B, 1), np.int64), target[:, :-1]], 1)   # token 0 = padding_idx: its embedding gets no gradient
+    reward = synth.uniform01(42, (B, L)).astype(np.float32)
+    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+    gen.zero_grad()
+    loss.backward()
+    oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, reward, padding_idx=0)
+    assert loss.item() == pytest.approx(oloss, rel=1e-5)
+    _cases.assert_grads_close(_grads_of(gen), ograds, rel=5e-5, what="edge %s" % ((V, E, H, B, L),))
+    assert not gen.embeddings.weight.grad[0].any()
+
+
 def test_pg_loss_rejects_unsupported_shapes_in_forward():
     gen = tg.modules.LSTMGenerator(48, 80, 100, 20).to(DEV)   # E, H not multiples of 32
     t = _t(synth.tokens(1, (4, 20), 100))
