@@ -780,6 +780,34 @@ def test_leak_reward_c1_shape_full_vs_oracle():
         assert torch.equal(comp[:, t, :, :given[t]], _t(sent)[:, :given[t]].expand(R, B, given[t]))
 
 
+@pytest.mark.parametrize("V,E,H,K,L,B,R,step", [(3, 32, 32, 16, 20, 1, 1, 4), (40, 32, 64, 8, 20, 3, 2, 5),
+                                                (150, 64, 128, 16, 24, 33, 1, 3), (9, 32, 32, 1, 20, 2, 3, 10),
+                                                (64, 48, 96, 5, 21, 5, 2, 7)])
+def test_leak_reward_edge_shapes_against_oracle(V, E, H, K, L, B, R, step):
+    """get_reward_leakgan on edge shapes: one sentence / one rollout, a three-word vocabulary, goal_size 1 and 5, hidden
+    sizes up to the supported 128, embedding width off the 32 grid, step sizes that do not divide L (the reference then
+    scores L // step_size prefixes), batches off every tile size -- against the oracle, live dropout included."""
+    gsd = synth.leak_state(V, E, H, K, 1720, B, seed=V + L, std=0.2)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=3)
+    gen = tg.modules.load_numpy_state(tg.modules.LeakGAN_G(E, H, V, L, goal_size=K, step_size=step, batch_size=B), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V, dropout=0.2), dsd, DEV)
+    og, od = oracle.Leak(gsd, step), oracle.Dis(dsd)
+    T = L // step
+    sent, u = synth.tokens(81, (B, L), V), synth.uniform01(82, (R, T, L, B))
+    du = synth.uniform01(83, (R * T, B, od.F))
+    o = oracle.get_reward_leakgan(og, od, sent, R, u, dropout_p=0.2, dropout_uniforms=du)
+    given = [t * step + 1 for t in range(T)]
+    replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(o["completions"]))
+    _cases.check_leak_token_parity(replay.cpu().numpy(), o["completions"], u, og, od)
+    rew, raw, comp = tg.ROLLOUT(gen).get_reward_leakgan(_t(sent), R, dis, 0, uniforms=_t(u), dropout_uniforms=_t(du),
+                                                        return_parts=True)
+    assert tuple(rew.shape) == (B, T)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * T, B)
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    if same.all():
+        np.testing.assert_allclose(rew.cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
+
+
 def test_concurrent_calls_on_two_streams():
     """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
     its own, run get_reward with different uniforms at the same time, several times over; each result must equal the
