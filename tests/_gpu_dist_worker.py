@@ -119,6 +119,31 @@ def gloo2(port, rank):
     if rank == 1:
         assert np.array_equal(gen.lstm2out.weight.detach().cpu().numpy(), _cases.gen_sd(c)["lstm2out.weight"])
     print("rank %d: sharded call equals the single-rank call" % rank, flush=True)
+    # uneven and empty shards: rollout_num 3 over two ranks (2 + 1) and rollout_num 1 (rank 1 owns nothing)
+    for R2 in (3, 1):
+        u2 = _t(tg.synth.uniform01(500 + R2, (R2, L, L, B)))
+        ro1 = tg.ROLLOUT(gen)
+        want = ro1.get_reward(_t(sent), R2, dis, uniforms=u2, return_parts=True)
+        got = ro.get_reward(_t(sent), R2, dis, uniforms=u2, return_parts=True)
+        p2 = tg.dist.ShardPlan.from_group(R2, ro.group)
+        assert got[2].shape[0] == p2.i_hi - p2.i_lo and torch.equal(got[2], want[2][p2.i_lo:p2.i_hi])
+        assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0])
+    print("rank %d: uneven and empty shards equal the single-rank call" % rank, flush=True)
+    # LeakGAN's reward shards the same way (rollout_num 2 of the golden, one rollout index per rank)
+    lc = _cases.load("leak_tiny")
+    lgsd, ldsd, lsent, lu, _ = _cases.leak_inputs(lc)
+    lgen = tg.modules.load_numpy_state(
+        tg.modules.LeakGAN_G(int(lc["E"]), int(lc["H"]), int(lc["V"]), int(lc["L"]), goal_size=int(lc["K"]),
+                             step_size=int(lc["step"]), batch_size=int(lc["B"])), lgsd, DEV)
+    ldis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, int(lc["V"])), ldsd, DEV).eval()
+    lwant = tg.ROLLOUT(lgen).get_reward_leakgan(_t(lsent), int(lc["R"]), ldis, 0, uniforms=_t(lu), return_parts=True)
+    lro = tg.ROLLOUT(lgen)
+    lro.group = tg.dist.WORLD
+    lgot = lro.get_reward_leakgan(_t(lsent), int(lc["R"]), ldis, 0, uniforms=_t(lu), return_parts=True)
+    lp = tg.dist.ShardPlan.from_group(int(lc["R"]), lro.group)
+    assert torch.equal(lgot[2], lwant[2][lp.i_lo:lp.i_hi])
+    assert torch.equal(lgot[1], lwant[1]) and torch.equal(lgot[0], lwant[0])
+    print("rank %d: sharded get_reward_leakgan equals the single-rank call" % rank, flush=True)
     # no explicit uniforms: private per-rank streams, so the two halves are different rollouts, not copies
     rew2, raw2, comp2 = ro.get_reward(_t(sent), R, dis, return_parts=True)
     mine = comp2[0, 0].cpu().contiguous()

@@ -113,7 +113,7 @@ class ROLLOUT:
             else:
                 u = uniforms.reshape(R, L, L, B)[plan.i_lo:plan.i_hi].contiguous()
             raw_local = torch.empty(Rl * L, B, dtype=torch.float32, device=dev)
-            comp = None
+            comp = torch.empty(0, L, B, L, dtype=torch.int64, device=dev)   # a rank that owns no rollout index
             if Rl > 0:
                 with self._timed("gen_rollout"):
                     comp = ops.gen_rollout(self.gen, sentences, Rl, u, precision=self.gen_precision)
@@ -214,7 +214,7 @@ class ROLLOUT:
             else:
                 u = uniforms.reshape(R, T, L, B)[plan.i_lo:plan.i_hi].contiguous()
             raw_local = torch.empty(Rl * T, B, dtype=torch.float32, device=dev)
-            comp = None
+            comp = torch.empty(0, T, B, L, dtype=torch.int64, device=dev)   # a rank that owns no rollout index
             if Rl > 0:
                 weights = _lib.dis_weights(dis, self.dis_precision)
                 F = weights[0].F
