@@ -808,6 +808,71 @@ def test_leak_reward_edge_shapes_against_oracle(V, E, H, K, L, B, R, step):
         np.testing.assert_allclose(rew.cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("ns,batch", [(1, 1), (1, 64), (5, 64), (64, 64), (130, 64), (7, 3)])
+def test_sample_num_batch_rule_and_edges(ns, batch):
+    """LSTMGenerator.sample's batching rule (generator.py:67: num_samples // batch_size + 1 batches unless the two are
+    equal, then truncate) on its edges, tokens against the oracle."""
+    V, L = 77, 20
+    gsd = synth.gen_state(V, 32, 32, seed=6, std=1.0)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    num_batch = ns // batch + 1 if ns != batch else 1
+    N = num_batch * batch
+    u = synth.uniform01(61, (L, N))
+    ref = oracle.gen_sample(oracle.Gen(gsd), N, L, 1, u)[:ns]
+    out = tg.generator.sample(gen, ns, batch, 1, uniforms=_t(u))
+    assert out.device.type == "cpu" and out.dtype == torch.int64 and tuple(out.shape) == (ns, L)
+    assert (out.numpy() == ref).all(-1).mean() >= 0.97 and (out.numpy() == ref).mean() >= 0.99
+
+
+def test_nll_edge_loaders():
+    """cal_nll over loaders the reference's GenDataIter can produce at its edges: a single batch of one sequence, batches
+    of unequal size (the mean is over batches, not tokens: metrics/nll.py:58-62), a one-token vocabulary tail."""
+    V, L = 45, 20
+    gsd = synth.gen_state(V, 32, 32, seed=8, std=0.7)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    for sizes in ([1], [3, 1], [64, 64, 5]):
+        batches, want = [], []
+        for i, n in enumerate(sizes):
+            tgt = synth.tokens(70 + i, (n, L), V)
+            inp = np.concatenate([np.ones((n, 1), np.int64), tgt[:, :-1]], 1)
+            batches.append({"input": torch.from_numpy(inp), "target": torch.from_numpy(tgt)})
+            want.append(-oracle.gen_teacher_forced(og, inp, tgt)["logp"].astype(np.float64).mean())
+        for precision in GEN_PRECISIONS:
+            got = tg.nll.cal_nll(gen, batches, precision=precision)
+            assert isinstance(got, float) and got == pytest.approx(round(float(np.mean(want)), 4), abs=1.01e-4)
+
+
+@pytest.mark.parametrize("B,R,p", [(1, 1, 0.25), (2, 5, 0.5), (33, 3, 0.0)])
+def test_mali_reward_edges(B, R, p):
+    """get_mali_reward with one sample, one mask, no dropout at all -- against the oracle (B = 1 normalises a single
+    value by itself: the reference's formula gives 0 there, and so must this)."""
+    V, L = 60, 20
+    sd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=4)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V, dropout=p), sd, DEV).train()
+    samples = synth.tokens(91, (B, L), V)
+    du = synth.uniform01(92, (R, B, dis.feature_dim))
+    rew = tg.maligan.get_mali_reward(dis, _t(samples), R, dropout_uniforms=_t(du)).cpu().numpy()
+    want = oracle.mali_reward(oracle.Dis(sd), samples, R, p, du)
+    assert rew.shape == (B, L)
+    np.testing.assert_allclose(rew, want, atol=2e-4 / B, rtol=2e-4)
+
+
+def test_get_token_reward_against_oracle():
+    """ROLLOUT.get_token_reward (utils/rollout.py:186-204): the mean over rollout_num completions from ONE given_num."""
+    c = _cases.load("reward_tiny_flat")
+    gen, dis = _gen(c), _dis(c).eval()
+    sent, u, _ = _cases.reward_inputs(c)
+    R, L, B = int(c["R"]), int(c["L"]), int(c["B"])
+    og, od = oracle.Gen(_cases.gen_sd(c)), oracle.Dis(_cases.dis_sd(c))
+    full = oracle.gen_rollout(og, sent, R, u)                    # [R, L, B, L]
+    for g in (1, 7, L):
+        want = np.stack([oracle.dis_forward(od, full[i, g - 1])["reward"] for i in range(R)]).mean(0)
+        got = tg.ROLLOUT(gen).get_token_reward(_t(sent), R, dis, 0, g, uniforms=_t(u))
+        assert tuple(got.shape) == (B,)
+        np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-4, rtol=0)
+
+
 def test_concurrent_calls_on_two_streams():
     """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
     its own, run get_reward with different uniforms at the same time, several times over; each result must equal the
