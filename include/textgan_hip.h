@@ -38,7 +38,9 @@ extern "C" {
  * matrices of TgDisWeights) must be 16-byte aligned -- torch parameters are (own allocations, 256-byte aligned);
  * a misaligned one is rejected with TG_ERR_ARG.  Workspaces must be 256-byte aligned.  Token, uniform and output
  * arrays need only their natural alignment (the scorer takes a slower exact-fp32 highway when its bias, output layer,
- * dropout uniforms or feature output are not 16-byte aligned). */
+ * dropout uniforms or feature output are not 16-byte aligned).
+ * Empty batches (N = 0, B = 0, or an empty rollout-index range) are no-ops that return TG_OK whatever the data
+ * pointers hold, as ATen handles a zero-row batch in the reference; negative sizes and rollout_num 0 are errors. */
 
 /* LSTMGenerator parameters: models/generator.py:33-35 (state_dict keys
  * embeddings.weight, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0,

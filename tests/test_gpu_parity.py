@@ -873,6 +873,26 @@ def test_get_token_reward_against_oracle():
         np.testing.assert_allclose(got.cpu().numpy(), want, atol=1e-4, rtol=0)
 
 
+def test_empty_batches_are_no_ops():
+    """Empty inputs behave as they do in the reference (ATen handles a zero-row batch): empty outputs of the right
+    shape, no error -- scorer, get_reward with no sentence, NLL, sample(0), MaliGAN reward, policy-gradient loss."""
+    V, L = 50, 20
+    gen = tg.modules.synthetic_generator(V, 32, 32, L, device=DEV)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=DEV)
+    e = torch.zeros(0, L, dtype=torch.long, device=DEV)
+    r = tg.ops.dis_score(dis, e, want_logits=True, want_feature=True)
+    assert tuple(r["reward"].shape) == (0,) and tuple(r["logits"].shape) == (0, 2) and tuple(r["feature"].shape) == (0, 1720)
+    assert tuple(tg.discriminator.forward(dis, e).shape) == (0, 2)
+    assert tuple(tg.ROLLOUT(gen).get_reward(e, 2, dis).shape) == (0, L)
+    assert tuple(tg.ops.gen_nll(gen, e, e).shape) == (0, L)
+    assert tuple(tg.generator.sample(gen, 0, 4, 1).shape) == (0, L)
+    assert tuple(tg.maligan.get_mali_reward(dis, e, 2).shape) == (0, L)
+    loss = tg.pgloss.batchPGLoss(gen, e, e, torch.zeros(0, L, device=DEV))
+    assert loss.item() == 0.0
+    with pytest.raises(RuntimeError):          # rollout_num 0: the reference divides by it (NaN rewards); refused here
+        tg.ROLLOUT(gen).get_reward(torch.zeros(3, L, dtype=torch.long, device=DEV), 0, dis)
+
+
 def test_concurrent_calls_on_two_streams():
     """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
     its own, run get_reward with different uniforms at the same time, several times over; each result must equal the

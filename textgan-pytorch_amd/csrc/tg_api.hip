@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void k_reward_reduce(const float* __restrict__
 }
 
 extern "C" int tg_reward_reduce(const float* raw, int B, int L, int R, float* out, void* stream) {
+    if (B == 0 && L >= 1 && R >= 1) return TG_OK;   // an empty batch: no reward to write
     if (!raw || !out || B < 1 || L < 1 || R < 1) {
         tg_set_error("tg_reward_reduce: bad arguments (B=%d L=%d R=%d)", B, L, R);
         return TG_ERR_ARG;

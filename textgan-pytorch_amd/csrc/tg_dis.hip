@@ -1456,7 +1456,7 @@ int launch_highway_frag(Hw2Args& a, int MBp, int N, hipStream_t stream) {
 int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const int64_t* sentences, int B, int col,
                float dropout_p, const float* dropout_uniforms, float* reward_out, float* logits_out,
                float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream, bool reuse = false) {
-    if (N < 0 || L < 1 || !seqs) {
+    if (N < 0 || L < 1 || (N > 0 && !seqs)) {   // an empty batch is a no-op
         tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
     }
@@ -1690,7 +1690,7 @@ __global__ __launch_bounds__(256) void k_dis_rescore(const RescoreArgs a) {
 extern "C" int tg_dis_rescore_dropout(const TgDisWeights* w, const float* feature, int N, int R, int col,
                                       float dropout_p, const float* dropout_uniforms, float* reward_out,
                                       void* stream) {
-    if (!w || !w->out_w || !w->out_b || !feature || !reward_out || N < 0 || R < 1) {
+    if (!w || !w->out_w || !w->out_b || (N > 0 && (!feature || !reward_out)) || N < 0 || R < 1) {
         tg_set_error("tg_dis_rescore_dropout: bad arguments (N=%d R=%d)", N, R);
         return TG_ERR_ARG;
     }
@@ -1762,6 +1762,7 @@ extern "C" size_t tg_dis_score_rollout_workspace_bytes(const TgDisWeights* w, in
 extern "C" int tg_dis_score_rollout(const TgDisWeights* w, const int64_t* sentences, const int64_t* completions,
                                     int B, int L, int R, int col, float dropout_p, const float* dropout_uniforms,
                                     float* reward_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (B == 0 && R >= 0 && L >= 1) return TG_OK;   // no sentence: nothing to score
     if (!sentences || B < 1 || R < 0 || (long)R * L * B > 0x7fffffffL) {
         tg_set_error("tg_dis_score_rollout: bad arguments (B=%d L=%d R=%d)", B, L, R);
         return TG_ERR_ARG;

@@ -1059,7 +1059,7 @@ extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, 
                                      void* stream) {
     int rc = check_weights(w);
     if (rc) return rc;
-    if (!inp || N < 0 || L < 1) {
+    if (N < 0 || L < 1 || (N > 0 && !inp)) {   // an empty batch (N = 0, any pointers) is a no-op
         tg_set_error("tg_gen_teacher_forced: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
     }
@@ -1096,7 +1096,7 @@ extern "C" int tg_gen_teacher_forced_ws(const TgGenWeights* w, const int64_t* in
     if (sup == 0)
         return tg_gen_teacher_forced(w, inp, target, N, L, logp_out, lse_out, logits_out, states_out, stream);
     if (sup < 0) return check_weights(w);
-    if (!inp || N < 0 || L < 1 || (size_t)N * L >= ((size_t)1 << 31) - 256) {
+    if (N < 0 || L < 1 || (N > 0 && !inp) || (size_t)N * L >= ((size_t)1 << 31) - 256) {
         tg_set_error("tg_gen_teacher_forced_ws: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
     }
@@ -1114,7 +1114,7 @@ extern "C" int tg_gen_nll(const TgGenWeights* w, const int64_t* inp, const int64
                           float* logp_out, float* lse_out, void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_weights(w, true);
     if (rc) return rc;
-    if (!inp || !target || !logp_out || N < 0 || L < 1) {
+    if (N < 0 || L < 1 || (N > 0 && (!inp || !target || !logp_out))) {
         tg_set_error("tg_gen_nll: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
     }
@@ -1162,13 +1162,14 @@ extern "C" int tg_gen_rollout(const TgGenWeights* w, const int64_t* sentences, i
                               void* workspace, size_t workspace_bytes, void* stream) {
     int rc = check_weights(w, true);
     if (rc) return rc;
-    if (!sentences || !uniforms || !completions || B < 1 || L < 1 || R < 1 || g_lo < 1 || g_hi > L || g_lo > g_hi ||
-        i_lo < 0 || i_hi > R || i_lo > i_hi) {
+    const bool empty = B == 0 || i_lo == i_hi;   // no sentence or no rollout index: a no-op, whatever the pointers
+    if ((!empty && (!sentences || !uniforms || !completions)) || B < 0 || L < 1 || R < 1 || g_lo < 1 || g_hi > L ||
+        g_lo > g_hi || i_lo < 0 || i_hi > R || i_lo > i_hi) {
         tg_set_error("tg_gen_rollout: bad arguments (B=%d L=%d R=%d g=[%d,%d] i=[%d,%d))", B, L, R, g_lo, g_hi, i_lo,
                      i_hi);
         return TG_ERR_ARG;
     }
-    if (i_lo == i_hi) return TG_OK;
+    if (empty) return TG_OK;
     if (!workspace || workspace_bytes < tg_gen_rollout_workspace_bytes(w, B, L, i_hi - i_lo)) {
         tg_set_error("tg_gen_rollout: workspace too small (%zu < %zu)", workspace_bytes,
                      tg_gen_rollout_workspace_bytes(w, B, L, i_hi - i_lo));

@@ -124,7 +124,7 @@ class ROLLOUT:
                 if p > 0 and dropout_uniforms is not None:
                     du_all = dropout_uniforms.reshape(R * L * B, F)[plan.i_lo * L * B:plan.i_hi * L * B]
                 # whole rollouts per scorer call, at most dis_chunk sequences each
-                step = max(1, self.dis_chunk // (L * B))
+                step = max(1, self.dis_chunk // max(1, L * B))
                 with self._timed("dis_score"):
                     for lo in range(0, Rl, step):
                         hi = min(Rl, lo + step)
