@@ -176,6 +176,30 @@ def test_get_reward_edge_shapes_against_oracle(V, B, L, R, precision):
     assert torch.equal(comp[:, L - 1], _t(sent).expand(R, B, L))
 
 
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+@pytest.mark.parametrize("V,E,H", [(200, 32, 32), (5255, 32, 32), (900, 64, 96)])
+def test_rollout_uniform_extremes(V, E, H, precision):
+    """Uniforms at the ends of [0, 1): u = 0 draws the first entry with a non-zero probability, u = 1 - 2^-24 the last
+    one the CDF reaches; a mix of both, of exact powers of two and of ordinary values must match the oracle's tokens."""
+    if precision == "fp32" and tg._lib.lib().tg_gen_supported(V, E, H) == 1:
+        pytest.skip("hidden size outside the fp32 kernels' set")
+    B, L, R = 5, 20, 2
+    gsd = synth.gen_state(V, E, H, seed=14, std=1.0 if H == 32 else 0.3)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    og = oracle.Gen(gsd)
+    sent = synth.tokens(51, (B, L), V)
+    u = synth.uniform01(52, (R, L, L, B)).copy()
+    flat = u.reshape(-1)
+    flat[0::7] = 0.0
+    flat[1::7] = np.float32(1.0) - np.float32(2.0 ** -24)
+    flat[2::7] = 0.5
+    flat[3::7] = np.float32(2.0 ** -20)
+    ref = oracle.gen_rollout(og, sent, R, u)
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(ref), precision=precision).cpu().numpy()
+    _cases.check_token_parity(replay, ref, u, og)
+    assert replay.min() >= 0 and replay.max() < V
+
+
 # ------------------------------------------------------------------ generator beyond E = H = 32 (tg_genw.hip)
 WIDE_CASES = [
     # V, E, H, B, L, R, std -- the canonical sampler has more than 16 groups per span above V = 16384, B*R*L and V
