@@ -917,6 +917,24 @@ def test_empty_batches_are_no_ops():
         tg.ROLLOUT(gen).get_reward(torch.zeros(3, L, dtype=torch.long, device=DEV), 0, dis)
 
 
+def test_out_of_range_tokens_are_clamped_not_faulted():
+    """Token ids outside [0, V) -- the reference raises IndexError from the embedding -- are clamped to the nearest valid
+    id for memory safety: the call completes and equals the call on the clamped sentences."""
+    V, L, B, R = 40, 20, 6, 2
+    gen = tg.modules.synthetic_generator(V, 32, 32, L, device=DEV)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=DEV).eval()
+    sent = synth.tokens(3, (B, L), V)
+    bad = sent.copy()
+    bad[0, 0], bad[1, 5], bad[2, 19], bad[3, 7] = -1, V, V + 1000, -(2 ** 40)
+    u = _t(synth.uniform01(4, (R, L, L, B)))
+    want = tg.ROLLOUT(gen).get_reward(_t(np.clip(bad, 0, V - 1)), R, dis, uniforms=u)
+    got = tg.ROLLOUT(gen).get_reward(_t(bad), R, dis, uniforms=u)
+    assert torch.isfinite(got).all() and torch.equal(got, want)
+    a = tg.ops.dis_score(dis, _t(bad))["reward"]
+    b = tg.ops.dis_score(dis, _t(np.clip(bad, 0, V - 1)))["reward"]
+    assert torch.equal(a, b)
+
+
 def test_concurrent_calls_on_two_streams():
     """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
     its own, run get_reward with different uniforms at the same time, several times over; each result must equal the
