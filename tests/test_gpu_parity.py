@@ -935,6 +935,24 @@ def test_out_of_range_tokens_are_clamped_not_faulted():
     assert torch.equal(a, b)
 
 
+def test_strided_and_int32_token_inputs():
+    """Sentences given as a strided view or as int32 (a loader's dtype) give the result of the contiguous int64 call."""
+    V, L, B, R = 40, 20, 6, 2
+    gen = tg.modules.synthetic_generator(V, 32, 32, L, device=DEV)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=0, device=DEV).eval()
+    sent = _t(synth.tokens(3, (B, L), V))
+    u = _t(synth.uniform01(4, (R, L, L, B)))
+    want = tg.ROLLOUT(gen).get_reward(sent, R, dis, uniforms=u)
+    wide = torch.zeros(B, 2 * L, dtype=torch.long, device=DEV)
+    wide[:, ::2] = sent
+    view = wide[:, ::2]
+    assert not view.is_contiguous()
+    assert torch.equal(tg.ROLLOUT(gen).get_reward(view, R, dis, uniforms=u), want)
+    assert torch.equal(tg.ROLLOUT(gen).get_reward(sent.int(), R, dis, uniforms=u), want)
+    assert torch.equal(tg.discriminator.forward(dis, view), tg.discriminator.forward(dis, sent))
+    assert torch.equal(tg.ops.gen_nll(gen, view, sent.int()), tg.ops.gen_nll(gen, sent, sent))
+
+
 def test_concurrent_calls_on_two_streams():
     """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
     its own, run get_reward with different uniforms at the same time, several times over; each result must equal the
