@@ -176,13 +176,11 @@ def test_get_reward_edge_shapes_against_oracle(V, B, L, R, precision):
     assert torch.equal(comp[:, L - 1], _t(sent).expand(R, B, L))
 
 
-@pytest.mark.parametrize("precision", GEN_PRECISIONS)
-@pytest.mark.parametrize("V,E,H", [(200, 32, 32), (5255, 32, 32), (900, 64, 96)])
+@pytest.mark.parametrize("V,E,H,precision", [(200, 32, 32, "fp32"), (200, 32, 32, "split_f16"), (5255, 32, 32, "fp32"),
+                                             (5255, 32, 32, "split_f16"), (900, 64, 64, "fp32"), (900, 64, 96, "split_f16")])
 def test_rollout_uniform_extremes(V, E, H, precision):
     """Uniforms at the ends of [0, 1): u = 0 draws the first entry with a non-zero probability, u = 1 - 2^-24 the last
     one the CDF reaches; a mix of both, of exact powers of two and of ordinary values must match the oracle's tokens."""
-    if precision == "fp32" and tg._lib.lib().tg_gen_supported(V, E, H) == 1:
-        pytest.skip("hidden size outside the fp32 kernels' set")
     B, L, R = 5, 20, 2
     gsd = synth.gen_state(V, E, H, seed=14, std=1.0 if H == 32 else 0.3)
     gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
