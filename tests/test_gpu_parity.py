@@ -71,6 +71,28 @@ def test_teacher_forced_logits_and_nll(name):
             assert torch.equal(lp2, r["logp"])  # the same kernel as tg_gen_teacher_forced
 
 
+def test_generator_forward_surface():
+    """tg.generator.forward mirrors LSTMGenerator.forward's call shapes (generator.py:40-60): [N,T] and one-step [N]
+    inputs, need_hidden, the zero state of init_hidden; log-probabilities against the reference golden, the returned
+    state against the oracle; a carried (non-zero) state is refused."""
+    c = _cases.load("nll_tiny")
+    gen = _gen(c)
+    inp = c["inp"][:8]
+    pred, (h, cc) = tg.generator.forward(gen, _t(inp), gen.init_hidden(8), need_hidden=True)
+    N, L = inp.shape
+    assert tuple(pred.shape) == (N * L, int(c["V"])) and tuple(h.shape) == (1, N, gen.hidden_dim) == tuple(cc.shape)
+    if "logprobs" in c:
+        np.testing.assert_allclose(pred.view(N, L, -1).cpu().numpy(), c["logprobs"], rtol=1e-5, atol=2e-5)
+    o = oracle.gen_teacher_forced(oracle.Gen(_cases.gen_sd(c)), inp, want_logits=True, want_states=True)
+    np.testing.assert_allclose(h[0].cpu().numpy(), o["states"][L][:, 0], atol=1e-4)
+    np.testing.assert_allclose(cc[0].cpu().numpy(), o["states"][L][:, 1], atol=1e-4)
+    one = tg.generator.forward(gen, _t(inp[:, 0]))              # 1-D input: a single step
+    assert tuple(one.shape) == (N, int(c["V"]))
+    np.testing.assert_allclose(one.cpu().numpy(), pred.view(N, L, -1)[:, 0].cpu().numpy(), rtol=1e-6, atol=1e-6)
+    with pytest.raises(RuntimeError, match="zero initial state"):
+        tg.generator.forward(gen, _t(inp), (h, cc))
+
+
 def test_teacher_forced_ragged_rows():
     # N not a multiple of the 32-row tile, N == 1, and prefix-state mode (no projection)
     V, L = 777, 7

@@ -29,3 +29,23 @@ def forward_logprobs(gen, inp):
         r = ops.gen_teacher_forced(gen, inp, want_lse=True, want_logits=True)
     N, L, V = r["logits"].shape
     return (r["logits"] - r["lse"].unsqueeze(-1)).view(N * L, V)
+
+
+def forward(gen, inp, hidden=None, need_hidden=False):
+    """LSTMGenerator.forward(inp, hidden, need_hidden) (models/generator.py:40-60) under no_grad: ``inp`` [N] (one
+    step, :48-49) or [N,T]; returns log-probabilities [(N*T), V] (row = n*T + t) and, with ``need_hidden``, the new
+    (h, c), each [1,N,H].  ``hidden`` must be None or the zero state of ``init_hidden`` -- what every caller outside
+    the rollout and ``sample`` (both replaced whole) passes; a carried state raises."""
+    if inp.dim() == 1:
+        inp = inp.unsqueeze(1)
+    if hidden is not None and any(bool(torch.count_nonzero(t)) for t in hidden):
+        raise RuntimeError("textgan_hip generator.forward: only the zero initial state is supported (the rollout and "
+                           "sample, which carry a state, are separate entry points)")
+    with torch.no_grad():
+        r = ops.gen_teacher_forced(gen, inp, want_lse=True, want_logits=True, want_states=need_hidden)
+    N, T, V = r["logits"].shape
+    pred = (r["logits"] - r["lse"].unsqueeze(-1)).view(N * T, V)
+    if not need_hidden:
+        return pred
+    last = r["states"][T]                       # [N, 2, H]: (h, c) after the last position
+    return pred, (last[:, 0].unsqueeze(0).contiguous(), last[:, 1].unsqueeze(0).contiguous())
