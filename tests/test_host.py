@@ -93,6 +93,41 @@ def test_shells_and_rollout_match_the_reference_contract():
         assert callable(getattr(ro, k)), k
 
 
+def test_install_binds_the_optional_surfaces():
+    """tg.install on stand-ins shaped like the reference's modules and classes: ROLLOUT replaced in the module, sample /
+    cal_nll / batchPGLoss / adv_loss bound on the classes with the reference's signatures, originals kept."""
+    import types
+    mod = types.SimpleNamespace(ROLLOUT=object)
+
+    class Gen(torch.nn.Module):
+        def sample(self, num_samples, batch_size, start_letter=1):
+            return "ref sample"
+
+    class NLL:
+        @staticmethod
+        def cal_nll(model, data_loader, criterion, gpu=True):
+            return "ref nll"
+
+    class SeqG(Gen):
+        def batchPGLoss(self, inp, target, reward):
+            return "ref pg"
+
+    class MaliG(Gen):
+        def adv_loss(self, inp, target, reward):
+            return "ref adv"
+
+    assert tg.install(mod, Gen, NLL, (SeqG, MaliG)) is tg.ROLLOUT and mod.ROLLOUT is tg.ROLLOUT
+    assert Gen._tg_original_sample(Gen(), 1, 1) == "ref sample" and NLL._tg_original_cal_nll(None, None, None) == "ref nll"
+    assert SeqG._tg_original_batchPGLoss(SeqG(), 0, 0, 0) == "ref pg" and MaliG._tg_original_adv_loss(MaliG(), 0, 0, 0) == "ref adv"
+    assert "adv_loss" not in SeqG.__dict__ and "batchPGLoss" not in MaliG.__dict__
+    g = tg.modules.synthetic_generator(30, 32, 32, 20, device="cpu")
+    g.__class__ = type("G2", (Gen,), {})            # a CPU generator: the bound methods reach the HIP path and refuse
+    with pytest.raises(RuntimeError):
+        g.sample(4, 4)
+    with pytest.raises(RuntimeError):
+        NLL.cal_nll(g, [{"input": torch.zeros(2, 20, dtype=torch.long), "target": torch.zeros(2, 20, dtype=torch.long)}], None)
+
+
 def test_rollout_attributes_mirror_reference():
     gen = tg.modules.synthetic_generator(50, 32, 32, 20, device="cpu")
     ro = tg.ROLLOUT(gen, gpu=True)

@@ -258,8 +258,41 @@ class _Timed:
         return False
 
 
-def install(rollout_module):
+def install(rollout_module, generator_class=None, nll_class=None, pg_classes=()):
     """Replace ``ROLLOUT`` in the reference's ``utils.rollout`` module (and thereby in every
-    instructor that does ``from utils.rollout import ROLLOUT`` afterwards)."""
+    instructor that does ``from utils.rollout import ROLLOUT`` afterwards).  Optionally bind the same-kernel
+    surfaces too, all by attribute on the reference's own classes (no reference file is edited):
+
+      generator_class  models.generator.LSTMGenerator: ``sample(num_samples, batch_size, start_letter)``
+                       (generator.py:62) -> tg.generator.sample (CPU int64 [n, L], as the reference returns)
+      nll_class        metrics.nll.NLL: the static ``cal_nll(model, data_loader, criterion, gpu)`` (nll.py:50)
+                       -> tg.nll.cal_nll
+      pg_classes       SeqGAN_G / SentiGAN_G (``batchPGLoss``) and MaliGAN_G (``adv_loss``): the policy-gradient loss
+                       with the fused forward / backward (tg.pgloss)
+
+    The replaced attributes are kept under ``_tg_original_<name>`` on the class."""
     rollout_module.ROLLOUT = ROLLOUT
+    from . import generator as _generator, nll as _nll, pgloss as _pgloss
+
+    def keep(cls, name):
+        if hasattr(cls, name) and not hasattr(cls, "_tg_original_" + name):
+            setattr(cls, "_tg_original_" + name, cls.__dict__.get(name, getattr(cls, name)))
+
+    if generator_class is not None:
+        keep(generator_class, "sample")
+
+        def sample(self, num_samples, batch_size, start_letter=1):
+            return _generator.sample(self, num_samples, batch_size, start_letter)
+        generator_class.sample = sample
+    if nll_class is not None:
+        keep(nll_class, "cal_nll")
+
+        def cal_nll(model, data_loader, criterion=None, gpu=True):
+            return _nll.cal_nll(model, data_loader, criterion, gpu)
+        nll_class.cal_nll = staticmethod(cal_nll)
+    for cls in pg_classes:
+        for name, fn in (("batchPGLoss", _pgloss.batchPGLoss), ("adv_loss", _pgloss.adv_loss)):
+            if name in cls.__dict__:
+                keep(cls, name)
+                setattr(cls, name, (lambda f: lambda self, inp, target, reward: f(self, inp, target, reward))(fn))
     return ROLLOUT
