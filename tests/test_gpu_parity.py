@@ -973,6 +973,36 @@ def test_strided_and_int32_token_inputs():
     assert torch.equal(tg.ops.gen_nll(gen, view, sent.int()), tg.ops.gen_nll(gen, sent, sent))
 
 
+def test_adversarial_generator_steps_like_the_instructor():
+    """SeqGANInstructor.adv_train_generator (instructor/oracle_data/seqgan_instructor.py:97-114) on the drop-in
+    surfaces alone: sample -> prepare (start letter prepended) -> ROLLOUT.get_reward -> batchPGLoss -> optimizer step,
+    three times.  The generator is stepped between calls: the same uniforms must give other completions afterwards
+    (parameters are read on every call), rewards stay probabilities, nothing goes non-finite."""
+    V, L, B, R = 300, 20, 16, 4
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L, name="seqgan"),
+                                      synth.gen_state(V, 32, 32, seed=2, std=0.5), DEV)
+    dis = tg.modules.synthetic_discriminator("seqgan", V, seed=1, device=DEV)
+    opt = torch.optim.Adam(gen.parameters(), lr=1e-2)
+    u = _t(synth.uniform01(5, (R, L, L, B)))
+    us = _t(synth.uniform01(6, (L, B)))
+    seen = []
+    for step in range(3):
+        target = tg.generator.sample(gen, B, B, 1, uniforms=us).to(DEV)           # CPU int64 [B, L] -> device
+        inp = torch.cat([torch.ones(B, 1, dtype=torch.long, device=DEV), target[:, :-1]], 1)  # GenDataIter.prepare
+        ro = tg.ROLLOUT(gen, True)                                               # a new ROLLOUT per step, as the instructor
+        rewards, raw, comp = ro.get_reward(target, R, dis, uniforms=u, return_parts=True)
+        assert tuple(rewards.shape) == (B, L) and bool(((raw >= 0) & (raw <= 1)).all())
+        loss = tg.pgloss.batchPGLoss(gen, inp, target, rewards)
+        assert torch.isfinite(loss)
+        opt.zero_grad()
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in gen.parameters())
+        opt.step()
+        seen.append((target.clone(), comp[:, 0].clone()))
+    assert not torch.equal(seen[0][0], seen[2][0])      # the stepped generator samples other sentences
+    assert not torch.equal(seen[0][1], seen[2][1])      # ... and rolls out other completions from the same uniforms
+
+
 def test_concurrent_calls_on_two_streams():
     """SURVEY 8(b) threading contract: the entry points are re-entrant per stream.  Two threads, each on a stream of
     its own, run get_reward with different uniforms at the same time, several times over; each result must equal the
