@@ -226,14 +226,38 @@ template <bool VEC>
 __device__ __forceinline__ f32x16 dot_seg(f32x16 acc, const float* __restrict__ arow, const float* __restrict__ brow,
                                           int K, int kk) {
     if constexpr (VEC) {
-#pragma unroll 2
-        for (int k = 0; k < K; k += 8) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(arow + k + 4 * kk);
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(brow + k + 4 * kk);
-            acc = TG_MFMA32(av[0], bv[0], acc);
-            acc = TG_MFMA32(av[1], bv[1], acc);
-            acc = TG_MFMA32(av[2], bv[2], acc);
-            acc = TG_MFMA32(av[3], bv[3], acc);
+        // blocks of U k-steps, the next block's 2U loads in flight under this block's 4U MFMAs: with one wave per SIMD
+        // and 40 workgroups on the chip (1 280 rows) nothing else hides the L2 latency of the operand rows
+        constexpr int U = 4;
+        f32x4 a0[U], b0[U], a1[U], b1[U];
+        const float* ap = arow + 4 * kk;
+        const float* bp = brow + 4 * kk;
+        auto load = [&](f32x4 (&av)[U], f32x4 (&bv)[U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + 8 * u < K) {
+                    av[u] = *reinterpret_cast<const f32x4*>(ap + k0 + 8 * u);
+                    bv[u] = *reinterpret_cast<const f32x4*>(bp + k0 + 8 * u);
+                }
+        };
+        auto mfma = [&](const f32x4 (&av)[U], const f32x4 (&bv)[U], int k0) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (k0 + 8 * u < K) {
+                    acc = TG_MFMA32(av[u][0], bv[u][0], acc);
+                    acc = TG_MFMA32(av[u][1], bv[u][1], acc);
+                    acc = TG_MFMA32(av[u][2], bv[u][2], acc);
+                    acc = TG_MFMA32(av[u][3], bv[u][3], acc);
+                }
+        };
+        load(a0, b0, 0);
+        for (int k = 0; k < K; k += 16 * U) {
+            load(a1, b1, k + 8 * U);
+            mfma(a0, b0, k);
+            if (k + 8 * U < K) {
+                load(a0, b0, k + 16 * U);
+                mfma(a1, b1, k + 8 * U);
+            }
         }
     } else {
         for (int k = 0; k < K; k += 2) {
