@@ -440,16 +440,31 @@ __global__ __launch_bounds__(256) void k_leak_proj(LeakArgs a) {
     const bool vec = (KH % 8 == 0) && (K % 8 == 0) && ((reinterpret_cast<uintptr_t>(a.w.w2g_w) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(a.w.w2g_b) & 15) == 0);
     if (vec) {
+        // the next k-step's four operand loads in flight under this step's 16 MFMAs
+        f32x4 av[2], bv[2], an[2], bn[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            av[q] = *reinterpret_cast<const f32x4*>(arow[q] + 4 * kk);
+            bv[q] = *reinterpret_cast<const f32x4*>(brow[q] + 4 * kk);
+        }
         for (int k = 0; k < KH; k += 8) {
-            f32x4 av[2], bv[2];
+            const int kn = k + 8 < KH ? k + 8 : k;   // the last step re-reads its own operands (never used)
+#pragma unroll
             for (int q = 0; q < 2; ++q) {
-                av[q] = *reinterpret_cast<const f32x4*>(arow[q] + k + 4 * kk);
-                bv[q] = *reinterpret_cast<const f32x4*>(brow[q] + k + 4 * kk);
+                an[q] = *reinterpret_cast<const f32x4*>(arow[q] + kn + 4 * kk);
+                bn[q] = *reinterpret_cast<const f32x4*>(brow[q] + kn + 4 * kk);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
+#pragma unroll
                 for (int qa = 0; qa < 2; ++qa)
+#pragma unroll
                     for (int qb = 0; qb < 2; ++qb) acc[qa][qb] = TG_MFMA32(av[qa][e], bv[qb][e], acc[qa][qb]);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                av[q] = an[q];
+                bv[q] = bn[q];
+            }
         }
         for (int k = 0; k < K; k += 8) {
             f32x4 av[2], bv[2];
