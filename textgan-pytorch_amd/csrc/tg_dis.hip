@@ -1249,7 +1249,7 @@ MergePlan plan_merge(const TgDisWeights* w) {
     return pl;
 }
 
-int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem) {
+int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem, int min_S = 1) {
     ca.w = *w;
     ca.L = L;
     ca.stamps = tg_diag_pointer("TG_CONV_STAMPS");
@@ -1257,8 +1257,11 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
     const int LP = L + pl.pad_rows;  // LDS rows per sequence
     int S = 32, log2S = 5;
     while (S > 1 && (size_t)LP * S * kERow * sizeof(float) + 64 > 144 * 1024) { S >>= 1; --log2S; }
-    // few sequences (the base sentences of the prefix pass): fewer per workgroup so that the grid fills the chip
-    while (S > 1 && (N + S - 1) / S < 512) { S >>= 1; --log2S; }
+    // few sequences: fewer per workgroup so that the grid fills the chip -- down to min_S (1 for the base sentences of
+    // the prefix pass; 8 where the pooled features are wanted: below that every workgroup streams all the weights for
+    // a handful of columns and the tiles are mostly time padding, so launch_conv_t widens the grid over the (width,
+    // tile) items instead)
+    while (S > min_S && (N + S - 1) / S < 512) { S >>= 1; --log2S; }
     if ((size_t)LP * S * kERow * sizeof(float) + 64 > 160 * 1024) {
         tg_set_error("tg_dis_score: sequence length %d too long for the LDS-resident conv kernel", L);
         return TG_ERR_ARG;
@@ -1309,9 +1312,10 @@ int launch_conv_t(const ConvArgs& ca, size_t sm, hipStream_t stream) {
     static TgLdsAttr attr;
     if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_dis_conv<MODE, SPLIT>), sm, "k_dis_conv")) return rc;
     tg_prof_begin(MODE == kConvStoreAll ? TG_KERNEL_DIS_PREFIX : TG_KERNEL_DIS_CONV, stream);
-    // a grid of fewer workgroups than CUs (the sentence pass: B sequences) is widened over the (width, tile) items
+    // a grid of fewer workgroups than CUs is widened over the (width, tile) items: the y workgroups of a sequence group
+    // gather the same embeddings and deal the items between them (every item writes features of its own)
     const int gx = (ca.N + ca.S - 1) / ca.S;
-    const int gy = (MODE == kConvStoreAll && gx < 256) ? tg_min_host(tg_min_host(8, ca.n_items), (512 + gx - 1) / gx) : 1;
+    const int gy = gx < 256 ? tg_min_host(tg_min_host(8, ca.n_items), (512 + gx - 1) / gx) : 1;
     hipLaunchKernelGGL((k_dis_conv<MODE, SPLIT>), dim3(gx, gy), dim3(kConvThreads), sm, stream, ca);
     tg_prof_end(stream);
     return TG_OK;
@@ -1487,7 +1491,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     // ---- conv
     ConvArgs ca = {};
     size_t sm = 0;
-    rc = prepare_conv(ca, w, sentences ? B : N, L, &sm);
+    rc = prepare_conv(ca, w, sentences ? B : N, L, &sm, sentences ? 1 : 8);
     if (rc) return rc;
     if (w->precision == TG_DIS_SPLIT_F16) {
         rc = prepare_split(ca, w, w16, scal, stream, reuse);
@@ -1534,7 +1538,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
         hipLaunchKernelGGL(k_dis_prefix_scan, dim3((B * w->F + 255) / 256), dim3(256), 0, stream, cv, B, L, w->F);
         tg_prof_end(stream);
-        rc = prepare_conv(ca, w, N, L, &sm);
+        rc = prepare_conv(ca, w, N, L, &sm, 8);
         if (rc) return rc;
         ca.seqs = seqs;
         ca.pooled = pooled;
