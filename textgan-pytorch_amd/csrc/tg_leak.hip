@@ -43,6 +43,7 @@ struct LeakArgs {
     float* rg;                 // [N,K] normalised goal2goal(real_goal) in force
     double* ring;              // [4][N][K] goal2goal(cur_goal) of the last four positions
     float* z;                  // [N, K*H + K] projection operand
+    float* mpre;               // [N, 4H] manager.weight_ih . feature of this position (k_leak_mgates)
     float* logits;             // [N,V]
     const double* prep;        // P [K*H], q [K], Q [H*H], c [H], s [1], gp [B*K]
     int given[kMaxT];
@@ -50,6 +51,7 @@ struct LeakArgs {
     int i0;                    // first rollout index of the chunk
     int pos;
     int Ls, GK, NG;            // canonical sampler geometry
+    long long* stamps;         // diagnostic (TG_LEAK_STAMPS, -DTG_DIAG=1): k_leak_cells phase cycles, [workgroup][8]
 };
 
 __device__ __forceinline__ void row_ids(const LeakArgs& a, int n, int& i, int& t, int& b) {
@@ -229,7 +231,7 @@ __device__ __forceinline__ f32x16 dot_seg(f32x16 acc, const float* __restrict__ 
         // blocks of U k-steps, the next block's 2U loads in flight under this block's 4U MFMAs: with one wave per SIMD
         // and 40 workgroups on the chip (1 280 rows) nothing else hides the L2 latency of the operand rows
         constexpr int U = 4;
-        f32x4 a0[U], b0[U], a1[U], b1[U];
+        f32x4 a0[U], b0[U], a1[U], b1[U], a2[U], b2[U];
         const float* ap = arow + 4 * kk;
         const float* bp = brow + 4 * kk;
         auto load = [&](f32x4 (&av)[U], f32x4 (&bv)[U], int k0) {
@@ -250,13 +252,20 @@ __device__ __forceinline__ f32x16 dot_seg(f32x16 acc, const float* __restrict__ 
                     acc = TG_MFMA32(av[u][3], bv[u][3], acc);
                 }
         };
+        // three register sets: the loads of the block after next are issued before this block's MFMAs
+        constexpr int BK = 8 * U;
         load(a0, b0, 0);
-        for (int k = 0; k < K; k += 16 * U) {
-            load(a1, b1, k + 8 * U);
+        load(a1, b1, BK);
+        for (int k = 0; k < K; k += 3 * BK) {
+            load(a2, b2, k + 2 * BK);
             mfma(a0, b0, k);
-            if (k + 8 * U < K) {
-                load(a0, b0, k + 16 * U);
-                mfma(a1, b1, k + 8 * U);
+            if (k + BK < K) {
+                load(a0, b0, k + 3 * BK);
+                mfma(a1, b1, k + BK);
+            }
+            if (k + 2 * BK < K) {
+                load(a1, b1, k + 4 * BK);
+                mfma(a2, b2, k + 2 * BK);
             }
         }
     } else {
@@ -277,9 +286,11 @@ __device__ __forceinline__ bool vec_ok(const void* p, int ld, int K) {
 // gates [4H][32 rows] = W_ih . x + W_hh . h for the workgroup's 32 rows -> LDS g[4H][33]; wave w takes gate tiles
 // w, w+4, ...  x rows: xrow(j) (K = nin, row-major), h rows: hprev + n*H.
 // xbase / hbase: the arrays the rows come from (their alignment decides the load width, uniformly for the wave).
+// pre != nullptr: W_ih . x was computed by k_leak_mgates (pre[n][4H], row of this lane = prow): only the recurrent
+// product runs here.
 __device__ void lstm_gates(const float* __restrict__ w_ih, int nin, const float* __restrict__ w_hh, int H,
                            const float* __restrict__ xrow, const float* xbase, const float* __restrict__ hrow,
-                           const float* hbase, float* g, int wave, int lane) {
+                           const float* hbase, float* g, int wave, int lane, const float* __restrict__ prow = nullptr) {
     const int i = lane & 31, kk = lane >> 5;
     const bool v1 = vec_ok(w_ih, nin, nin) && vec_ok(xbase, nin, nin);
     const bool v2 = vec_ok(w_hh, H, H) && vec_ok(hbase, H, H);
@@ -287,13 +298,45 @@ __device__ void lstm_gates(const float* __restrict__ w_ih, int nin, const float*
         f32x16 acc = {};
         const float* a1 = w_ih + (size_t)(tile * 32 + i) * nin;
         const float* a2 = w_hh + (size_t)(tile * 32 + i) * H;
-        acc = v1 ? dot_seg<true>(acc, a1, xrow, nin, kk) : dot_seg<false>(acc, a1, xrow, nin, kk);
+        if (!prow) acc = v1 ? dot_seg<true>(acc, a1, xrow, nin, kk) : dot_seg<false>(acc, a1, xrow, nin, kk);
         acc = v2 ? dot_seg<true>(acc, a2, hrow, H, kk) : dot_seg<false>(acc, a2, hrow, H, kk);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int gi = tile * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-            g[gi * 33 + i] = acc[r];
+            g[gi * 33 + i] = prow ? prow[gi] + acc[r] : acc[r];
         }
+    }
+}
+
+// ---- manager.weight_ih . feature for every row of the position: pre[n][4H].  One workgroup per (32 rows, 32 gate
+// rows); its four waves take a quarter of the K = G contraction each (the product is a chain of K/2 dependent MFMAs:
+// inside k_leak_cells, 40 workgroups of 4 waves, it was half of that kernel's time) and are summed through LDS in
+// segment order.
+__global__ __launch_bounds__(256) void k_leak_mgates(LeakArgs a) {
+    __shared__ float red[4][32][33];
+    const int H = a.w.H, G = a.w.G, N = a.N;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int i = lane & 31, kk = lane >> 5;
+    const int n0 = blockIdx.x * 32, tile = blockIdx.y;
+    const int nj = tg_min(n0 + i, N - 1);
+    const float* arow = a.w.m_wih + (size_t)(tile * 32 + i) * G;
+    const float* brow = a.feat + (size_t)nj * G;
+    const bool vec = vec_ok(a.w.m_wih, G, G) && vec_ok(a.feat, G, G);
+    f32x16 acc = {};
+    if (vec) {
+        const int seg_len = ((G / 8 + 3) / 4) * 8;
+        const int k_lo = tg_min(wave * seg_len, G), k_hi = tg_min(k_lo + seg_len, G);
+        acc = dot_seg<true>(acc, arow + k_lo, brow + k_lo, k_hi - k_lo, kk);
+    } else if (wave == 0) {
+        acc = dot_seg<false>(acc, arow, brow, G, kk);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kk][i] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int j = idx >> 5, gi = idx & 31;          // consecutive threads: consecutive gate rows of one row
+        if (n0 + j < N)
+            a.mpre[(size_t)(n0 + j) * 4 * H + tile * 32 + gi] = ((red[0][gi][j] + red[1][gi][j]) + red[2][gi][j]) + red[3][gi][j];
     }
 }
 
@@ -330,6 +373,7 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
     const int j = lane & 31;
     const int nj = tg_min(n0 + j, N - 1);   // loads of rows past the end read the last row; stores are guarded
 
+    const long long c0 = a.stamps ? tg_clock() : 0;
     // worker LSTM on the embedding of the token fed at this position
     int64_t tk = a.tok[nj];
     tk = tk < 0 ? 0 : (tk >= a.w.V ? a.w.V - 1 : tk);
@@ -337,25 +381,35 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
     __syncthreads();
     lstm_update(g, a.w.w_bih, a.w.w_bhh, H, a.hw, a.cw, hl, n0, N, tid);
     __syncthreads();
+    const long long c1 = a.stamps ? tg_clock() : 0;
     // z = temperature * [rg (x) h_w | rg], with the real goal in force BEFORE this position's update; temperature
     // 1.5 for idx <= 1, else 1.0 (train=True; LeakGAN_G.py:87-95)
     const float temp = a.pos > 1 ? 1.0f : a.w.temperature;
     const int ldz = K * H + K;
-    for (int idx = tid; idx < 32 * ldz; idx += kLThreads) {
-        const int r = idx / ldz, q = idx % ldz;
-        const int n = n0 + r;
-        if (n >= N) continue;
-        const float rgk = a.rg[(size_t)n * K + (q < K * H ? q / H : q - K * H)];
-        a.z[(size_t)n * ldz + q] = q < K * H ? temp * rgk * hl[r * (H + 1) + q % H] : temp * rgk;
+    // thread = column q of the operand (its goal index and hidden unit fixed once), loop over the 32 rows: no
+    // division inside the loop, the stores of a wave are 256 contiguous bytes of one row
+    const int rows = tg_min(32, N - n0);
+    for (int idx = tid; idx < rows * K; idx += kLThreads) g[idx] = a.rg[(size_t)n0 * K + idx];   // g is free here (<= 32 x 64)
+    __syncthreads();
+    for (int q = tid; q < ldz; q += kLThreads) {
+        const bool tail = q >= K * H;
+        const int kq = tail ? q - K * H : q / H, hq = tail ? 0 : q % H;
+        for (int r = 0; r < rows; ++r) {
+            const float rgk = g[r * K + kq];
+            a.z[(size_t)(n0 + r) * ldz + q] = tail ? temp * rgk : temp * rgk * hl[r * (H + 1) + hq];
+        }
     }
     __syncthreads();
 
+    const long long c2 = a.stamps ? tg_clock() : 0;
     // manager LSTM on the feature of the tokens so far
-    lstm_gates(a.w.m_wih, G, a.w.m_whh, H, a.feat + (size_t)nj * G, a.feat, a.hm + (size_t)nj * H, a.hm, g, wave, lane);
+    lstm_gates(a.w.m_wih, G, a.w.m_whh, H, a.feat + (size_t)nj * G, a.feat, a.hm + (size_t)nj * H, a.hm, g, wave, lane,
+               a.mpre + (size_t)nj * 4 * H);
     __syncthreads();
     lstm_update(g, a.w.m_bih, a.w.m_bhh, H, a.hm, a.cm, hl, n0, N, tid);
     __syncthreads();
 
+    const long long c3 = a.stamps ? tg_clock() : 0;
     // goal2goal(cur_goal) = (P h_m + q) / max(||W h_m + b||, 1e-12), fp64; 8 threads per row
     const double* P = a.prep;
     const double* q = P + K * H;
@@ -405,6 +459,11 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
             rn = rn < 1e-12 ? 1e-12 : rn;
             for (int k = 0; k < K; ++k) a.rg[(size_t)n * K + k] = (float)(pk[r * K + k] / rn);
         }
+    }
+    if (a.stamps && tid == 0) {
+        const long long c4 = tg_clock();
+        long long* o = a.stamps + (size_t)blockIdx.x * 8;
+        o[0] += c1 - c0; o[1] += c2 - c1; o[2] += c3 - c2; o[3] += c4 - c3; o[4] += 1;
     }
 }
 
@@ -508,7 +567,7 @@ __global__ __launch_bounds__(256) void k_leak_proj(LeakArgs a) {
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LeakLayout {
-    size_t fed, tok, feat, hw, cw, hm, cm, rg, ring, z, logits, prep, dis, total;
+    size_t fed, tok, feat, hw, cw, hm, cm, rg, ring, z, mpre, logits, prep, dis, total;
     int rows;  // rows of one chunk
 };
 
@@ -540,6 +599,7 @@ LeakLayout layout(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, i
     o.rg = take(N * K * sizeof(float));
     o.ring = take(4 * N * K * sizeof(double));
     o.z = take(N * ((size_t)K * H + K) * sizeof(float));
+    o.mpre = take(N * (size_t)4 * H * sizeof(float));
     o.logits = take(N * (size_t)g->V * sizeof(float));
     o.prep = take(((size_t)K * H + K + (size_t)H * H + H + 1 + (size_t)B * K) * sizeof(double));
     o.dis = take(tg_dis_workspace_bytes(d, (int)N, L));
@@ -631,6 +691,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     a.rg = reinterpret_cast<float*>(ws + lo.rg);
     a.ring = reinterpret_cast<double*>(ws + lo.ring);
     a.z = reinterpret_cast<float*>(ws + lo.z);
+    a.mpre = reinterpret_cast<float*>(ws + lo.mpre);
     a.logits = reinterpret_cast<float*>(ws + lo.logits);
     a.prep = reinterpret_cast<const double*>(ws + lo.prep);
     for (int t = 0; t < T; ++t) a.given[t] = given_nums[t];
@@ -641,6 +702,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     a.Ls = span_len(g->V);
     const int NT = a.Ls / 16;
     a.GK = 1;
+    a.stamps = tg_diag_pointer("TG_LEAK_STAMPS");
     while ((NT + a.GK - 1) / a.GK > 16 && a.GK < 8) a.GK *= 2;
     a.NG = (NT + a.GK - 1) / a.GK;
     const int H = g->H, K = g->K;
@@ -678,6 +740,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
             if (rc) return rc;
             prepared_n = a.N;
             tg_prof_begin(TG_KERNEL_LEAK_CELLS, stream);
+            hipLaunchKernelGGL(k_leak_mgates, dim3((a.N + 31) / 32, (4 * g->H) / 32), dim3(256), 0, stream, a);
             hipLaunchKernelGGL(k_leak_cells, dim3((a.N + kLRows - 1) / kLRows), dim3(kLThreads), sm_cells, stream, a);
             tg_prof_end(stream);
             tg_prof_begin(TG_KERNEL_LEAK_PROJ, stream);
