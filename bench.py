@@ -14,14 +14,64 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
+
+
+def _requested_gpus(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
+def self_launch(argv):
+    """`python bench.py --gpus N` without a launcher (no WORLD_SIZE in the environment): start the N ranks the way the
+    driver does -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...`
+    -- as a CHILD process, before this process has imported torch or made any GPU call (it never does: it only
+    relays), and pass rank 0's one JSON line through.  Returns the exit status to leave with."""
+    import socket
+    n = _requested_gpus(argv)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this host
+    env["TG_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    print("bench.py: no launcher in the environment, starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr,
+          flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env)
+    line = None
+    for raw in proc.stdout:                                 # stderr of the ranks goes straight through
+        txt = raw.decode(errors="replace").strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            line = txt
+        elif txt:
+            print(txt, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        rc = 1
+        print("bench.py: the ranks ended without a JSON line", file=sys.stderr)
+    return rc
+
+
+if __name__ == "__main__" and _requested_gpus(sys.argv[1:]) > 1 and "WORLD_SIZE" not in os.environ:
+    sys.exit(self_launch(sys.argv[1:]))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
 sys.path.insert(0, ROOT)
 import textgan_pytorch_amd as tg  # noqa: E402
 
@@ -340,7 +390,9 @@ def run_rollout(args, name, world, rank, dev, steps, warmup):
         ro.generator.manual_seed(1234 + 100 * gi)   # the same seed on every rank: the library derives per-rank streams
         if world > 1:
             ro.group = tg.dist.WORLD                # shard the rollout index over the ranks (opt-in); weights are
-            ro.sync_weights = True                  # broadcast from rank 0 at the top of every call (once per step)
+            # broadcast from rank 0 at the top of every call (once per step); the k generators of a SentiGAN step share
+            # one D that nobody steps between their calls, so only the first call of a step carries it
+            ro.sync_weights = True if gi == 0 else "gen"
         ro.dis_precision = args.dis_precision
         ro.gen_precision = args.gen_precision
         if args.dropout_rng:
@@ -365,6 +417,8 @@ def run_rollout(args, name, world, rank, dev, steps, warmup):
     barrier()
     tg._lib.profile_enable(True)
     tg._lib.profile_read()
+    for ro in ros:
+        ro.timers = {}               # per-phase events on the launch stream (two event records per phase and call)
     t0 = time.perf_counter()
     for _ in range(steps):
         rewards = step()
@@ -372,10 +426,18 @@ def run_rollout(args, name, world, rank, dev, steps, warmup):
     dt = time.perf_counter() - t0
     prof = tg._lib.profile_read()
     tg._lib.profile_enable(False)
+    # per-phase milliseconds per step on this rank's stream: weight broadcast, shard compute (generator + scorer),
+    # the all-gather of the raw rows, the view(B,L,R).mean reduce; what is left of the step is host time
+    phase_names = ("sync_weights", "gen_rollout", "dis_score", "exchange", "reduce")
+    phase_ms = [sum(a.elapsed_time(b) for ro in ros for a, b in ro.timers.get(k, [])) / steps for k in phase_names]
+    for ro in ros:
+        ro.timers = None
+    phase_max = list(phase_ms)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        t = torch.tensor([dt] + phase_ms, dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = float(t[0].item())
+        phase_max = [float(x) for x in t[1:].tolist()]
     assert tuple(rewards.shape) == (B, L) and bool(torch.isfinite(rewards).all())
     del ros, gens, dis, rewards
     torch.cuda.empty_cache()
@@ -439,6 +501,11 @@ def run_rollout(args, name, world, rank, dev, steps, warmup):
                      # against the measured sustained rate of the same MFMA with real operands (power-limited clock)
                      "issued_frac_of_sustained": (ach * issue_factor[dom] / SUSTAINED_F16_MFMA_TFLOPS) if f16[dom] else None},
         "kernels": kernels,
+        # stream time per step and phase (hipEvents around each phase of ROLLOUT.get_reward): rank 0's own and the
+        # slowest rank's; `host_and_gaps` = the step's wall time not covered by them on the slowest rank
+        "phases": {"unit": "ms per step", "rank0": dict(zip(phase_names, phase_ms)),
+                   "max_over_ranks": dict(zip(phase_names, phase_max)),
+                   "host_and_gaps": dt / steps * 1e3 - sum(phase_max)},
     }
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(wl)
@@ -483,11 +550,22 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d"
-                         % (args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start `python bench.py --gpus %d` without a launcher (it starts "
+                         "its own ranks) or under torch.distributed.run --nproc-per-node %d"
+                         % (args.gpus, world, args.gpus, args.gpus))
     # TG_BENCH_REHEARSE=1: every rank on GPU 0 over gloo -- a rehearsal of the N > 1 code path on a one-GPU box (RCCL
     # refuses two ranks on one device); the numbers of such a run mean nothing
     rehearse = os.environ.get("TG_BENCH_REHEARSE") == "1"
+    if os.environ.get("TG_BENCH_DRYRUN") == "1":
+        # launcher / rendezvous / relay check for machines without a GPU (tests/test_host.py): no measurement at all
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo")
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            emit({"metric": "MC rollout completions/sec", "dry_run": True, "n_gpus": world})
+        return
     if rehearse:
         local_rank = 0
     torch.cuda.set_device(local_rank)

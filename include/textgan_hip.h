@@ -137,12 +137,15 @@ int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp,
  * outside the persistent kernel's set: H = 96, 160, 768, ... -- runs the pass as exact-fp32 GEMMs on
  * v_mfma_f32_32x32x2_f32 (tg_pgw.hip: per position the gates GEMM + cell, then the projection over chunks of (t, n)
  * rows with log-sum-exp and the target's logit per row).  Same outputs, same fp32 arithmetic contract.
+ *   states_in  [N,2,H] fp32 or NULL: the (h, c) the pass starts from -- LSTMGenerator.forward's `hidden` argument
+ *              (models/generator.py:40-51 accepts any state, not only init_hidden's zeros); NULL = zeros.  With
+ *              states_out, slot 0 then holds this state.  16-byte aligned.  (ABI 0.3: inserted after L.)
  *   workspace  tg_gen_teacher_forced_workspace_bytes(w, N, L, logits_out != NULL, states_out != NULL) bytes */
 size_t tg_gen_teacher_forced_workspace_bytes(const TgGenWeights* w, int N, int L, int have_logits_out,
                                              int have_states_out);
 int tg_gen_teacher_forced_ws(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
-                             float* logp_out, float* lse_out, float* logits_out, float* states_out,
-                             void* workspace, size_t workspace_bytes, void* stream);
+                             const float* states_in, float* logp_out, float* lse_out, float* logits_out,
+                             float* states_out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * NLL pass: tg_gen_teacher_forced restricted to what NLL.cal_nll needs (metrics/nll.py:49-63: the log-probability
@@ -209,7 +212,11 @@ int tg_gen_sample(const TgGenWeights* w, int N, int L, int64_t start_letter,
  * fragments) is a static device array of tg_gen_sample_static_bytes() = 2 621 696 bytes that every GPU the library
  * runs on holds until the process ends.  Limits: E = H = 32, TG_GEN_SPLIT_F16, V <= TG_STATIC_MAX_V (TG_ERR_ARG with
  * a message otherwise).  Calls no hipMalloc / hipFree.  All calls on one GPU share that GPU's array: two calls that
- * overlap on one GPU (different streams, different threads) race -- serialise them. */
+ * overlap on one GPU (different streams, different threads) race -- serialise them.
+ * Under HIP graph capture: make ONE ordinary call per device outside capture first.  The first call on a device
+ * resolves the array's address (hipGetSymbolAddress under a host mutex), the first launch of each kernel
+ * instantiation sets its dynamic-LDS attribute (hipFuncSetAttribute) and loads the code object -- none of which
+ * belongs inside a capturing stream; later calls only enqueue kernels and one hipMemsetAsync on `stream`. */
 #define TG_STATIC_MAX_V 16384
 size_t tg_gen_sample_static_bytes(void);
 int tg_gen_sample_static(const TgGenWeights* w, int N, int L, int64_t start_letter,

@@ -111,6 +111,27 @@ def _check_ties(idx, got, ref, uniforms, logits_of, tie_tol, max_check, draws, w
     st["max_tie_gap"] = max(st["max_tie_gap"], worst)
 
 
+def check_sample_token_parity(got_replay, ref, uniforms, gen_oracle, start_letter=1, min_agree=0.999, tie_tol=1e-6,
+                              max_check=1000, what=None):
+    """check_token_parity for LSTMGenerator.sample (models/generator.py:62-84): got_replay / ref [N,L] (got_replay
+    produced with forced=ref), uniforms [L,N]; every position is a draw, position t from the logits after feeding
+    [start_letter, ref[:t]].  >= 99.9 % identical and every disagreement a CDF tie within tie_tol."""
+    from oracle import oracle
+    N, L = ref.shape
+    diff = got_replay != ref
+    agree = 1.0 - diff.sum() / max(1, diff.size)
+    assert agree >= min_agree, "step-wise token agreement %.6f" % agree
+
+    def logits_of(i, gi, n, t):
+        inp = np.concatenate([[start_letter], ref[n, :-1]]).astype(np.int64)
+        return oracle.gen_teacher_forced(gen_oracle, inp[None, :], want_logits=True)["logits"][0, t]
+
+    idx = np.array([(0, 0, n, t) for n, t in np.argwhere(diff)], dtype=np.int64).reshape(-1, 4)
+    _check_ties(idx, got_replay[None, None], ref[None, None], uniforms[None, None], logits_of, tie_tol, max_check,
+                int(diff.size), what)
+    return agree
+
+
 # ------------------------------------------------------------------ LeakGAN rollout (SURVEY 8(f)4)
 def leak_inputs(c):
     """(LeakGAN_G state_dict, LeakGAN_D state_dict, sentences [B,L], uniforms [R,T,L,B], dropout uniforms or None)

@@ -85,6 +85,15 @@ def _sync_worker(rank, world, port, q):
                 for p in list(gen.parameters()) + list(dis.parameters()):
                     p.add_(0.01 * (rank + 1) * torch.randn_like(p))
         before = float(gen.lstm2out.weight.detach().abs().sum())
+        # per-module selection (ROLLOUT.sync_weights = "gen"): the generator arrives, the scorer is left as it is
+        ro0 = tg.ROLLOUT(gen)
+        ro0.group, ro0.sync_weights = tg.dist.WORLD, "gen"
+        ro0._sync(dis)
+        assert np.array_equal(gen.lstm2out.weight.detach().numpy(), _cases.gen_sd(c)["lstm2out.weight"])
+        assert np.array_equal(dis.highway.weight.detach().numpy(), _cases.dis_sd(c)["highway.weight"]) == (rank == 0)
+        ro0.sync_weights = "generator"
+        with pytest.raises(RuntimeError):
+            ro0._sync(dis)
         nbytes = tg.dist.sync_weights(gen, dis, tg.dist.WORLD, src=0)
         want = sum(p.numel() * 4 for m in (gen, dis) for p in m.parameters())
         assert nbytes == want, (nbytes, want)
@@ -106,6 +115,19 @@ def _sync_worker(rank, world, port, q):
         ro = tg.ROLLOUT(gen)
         mine = ro._rand((4, 8), "cpu", plan)
         again = tg.ROLLOUT(gen)._rand((4, 8), "cpu", plan)
+        # re-seeding reaches the private streams: another seed gives other draws, the first seed the first
+        torch.manual_seed(6)
+        other = ro._rand((4, 8), "cpu", plan)
+        assert not torch.equal(other, mine)
+        torch.manual_seed(5)
+        assert torch.equal(ro._rand((4, 8), "cpu", plan), mine)
+        ro.generator = torch.Generator().manual_seed(99)
+        g1 = ro._rand((4, 8), "cpu", plan)
+        ro.generator.manual_seed(99)
+        assert torch.equal(ro._rand((4, 8), "cpu", plan), ro._rand((4, 8), "cpu", plan)) is False
+        ro.generator = torch.Generator().manual_seed(99)
+        assert torch.equal(ro._rand((4, 8), "cpu", plan), g1)
+        ro.generator = None
         torch.manual_seed(5)
         single = ro._rand((4, 8), "cpu", tg.dist.ShardPlan(R))
         q.put((rank, before, full.numpy().copy(), mine.numpy().copy(), again.numpy().copy(), single.numpy().copy()))

@@ -73,8 +73,9 @@ def test_teacher_forced_logits_and_nll(name):
 
 def test_generator_forward_surface():
     """tg.generator.forward mirrors LSTMGenerator.forward's call shapes (generator.py:40-60): [N,T] and one-step [N]
-    inputs, need_hidden, the zero state of init_hidden; log-probabilities against the reference golden, the returned
-    state against the oracle; a carried (non-zero) state is refused."""
+    inputs, need_hidden, the zero state of init_hidden and a CARRIED (h, c): the reference accepts any hidden state.
+    Log-probabilities against the reference golden, the returned state against the oracle; a pass cut in two at any
+    position, the second half started from the first half's state, reproduces the golden's log-probabilities."""
     c = _cases.load("nll_tiny")
     gen = _gen(c)
     inp = c["inp"][:8]
@@ -89,8 +90,48 @@ def test_generator_forward_surface():
     one = tg.generator.forward(gen, _t(inp[:, 0]))              # 1-D input: a single step
     assert tuple(one.shape) == (N, int(c["V"]))
     np.testing.assert_allclose(one.cpu().numpy(), pred.view(N, L, -1)[:, 0].cpu().numpy(), rtol=1e-6, atol=1e-6)
-    with pytest.raises(RuntimeError, match="zero initial state"):
-        tg.generator.forward(gen, _t(inp), (h, cc))
+    # carried state: [0, cut) from zeros, [cut, L) from the state it returns -- the same arithmetic step by step
+    full = pred.view(N, L, -1)
+    for cut in (1, 7, L - 1):
+        p1, hid = tg.generator.forward(gen, _t(inp[:, :cut]), None, need_hidden=True)
+        p2, hid2 = tg.generator.forward(gen, _t(inp[:, cut:]), hid, need_hidden=True)
+        got = torch.cat([p1.view(N, cut, -1), p2.view(N, L - cut, -1)], 1)
+        assert torch.equal(got, full)
+        assert torch.equal(hid2[0], h) and torch.equal(hid2[1], cc)
+        if "logprobs" in c:
+            np.testing.assert_allclose(got.cpu().numpy(), c["logprobs"], rtol=1e-5, atol=2e-5)
+    # the step loop of LSTMGenerator.sample / rollout_mc_search written with forward(): token by token, state carried
+    hid, steps = None, []
+    for t in range(5):
+        out, hid = tg.generator.forward(gen, _t(inp[:, t]), hid, need_hidden=True)
+        steps.append(out)
+    assert torch.equal(torch.stack(steps, 1), full[:, :5])
+    # slot 0 of the exported states is the state the pass started from
+    st_in = torch.stack([h[0], cc[0]], 1).contiguous()
+    r = tg.ops.gen_teacher_forced(gen, _t(inp[:, :3]), want_logp=False, want_states=True, states_in=st_in)
+    assert torch.equal(r["states"][0], st_in)
+    with pytest.raises(RuntimeError, match="hidden must be"):
+        tg.generator.forward(gen, _t(inp), (h[:, :4], cc[:, :4]))
+
+
+@pytest.mark.parametrize("V,E,H", [(300, 64, 64), (900, 96, 160), (500, 32, 512)])
+def test_generator_forward_carried_state_other_shapes(V, E, H):
+    """The carried state on the generic persistent kernel (H = 64, 512) and on the GEMM formulation (H = 160): cut in two
+    == in one piece, and against the oracle from zeros."""
+    N, L = 9, 8
+    gsd = synth.gen_state(V, E, H, seed=4, std=0.2)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L), gsd, DEV)
+    inp = synth.tokens(9, (N, L), V)
+    full, (h, c) = tg.generator.forward(gen, _t(inp), None, need_hidden=True)
+    o = oracle.gen_teacher_forced(oracle.Gen(gsd), inp, want_logits=True, want_states=True)
+    lp = o["logits"] - o["lse"][..., None]
+    np.testing.assert_allclose(full.view(N, L, V).cpu().numpy(), lp, rtol=1e-5, atol=2e-5)
+    p1, hid = tg.generator.forward(gen, _t(inp[:, :3]), None, need_hidden=True)
+    p2, hid2 = tg.generator.forward(gen, _t(inp[:, 3:]), hid, need_hidden=True)
+    got = torch.cat([p1.view(N, 3, V), p2.view(N, L - 3, V)], 1)
+    np.testing.assert_allclose(got.cpu().numpy(), full.view(N, L, V).cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(hid2[0].cpu().numpy(), h.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(got.cpu().numpy(), lp, rtol=1e-5, atol=2e-5)
 
 
 def test_teacher_forced_ragged_rows():
@@ -147,7 +188,9 @@ def test_sample(name, precision):
     forced[:ns] = c["samples"]
     out = tg.ops.gen_sample(gen, N, L, int(c["start_letter"]), _t(u), forced=_t(forced),
                             precision=precision).cpu().numpy()[:ns]
-    assert (out == c["samples"]).mean() >= 0.999
+    # >= 99.9 % step-wise, and every disagreement a CDF tie (the rollout path's rule, north_star)
+    _cases.check_sample_token_parity(out, c["samples"].astype(np.int64), u[:, :ns], oracle.Gen(_cases.gen_sd(c)),
+                                     int(c["start_letter"]))
     s = tg.generator.sample(gen, ns, batch, int(c["start_letter"]), uniforms=_t(u))
     assert s.device.type == "cpu" and s.dtype == torch.int64 and tuple(s.shape) == (ns, L)
     assert (s.numpy() == c["samples"]).all(-1).mean() >= 0.98
@@ -192,8 +235,10 @@ def test_get_reward_edge_shapes_against_oracle(V, B, L, R, precision):
     assert tuple(rew.shape) == (B, L) and tuple(raw.shape) == (R * L, B)
     same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
     np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
-    if same.all():
-        np.testing.assert_allclose(rew.cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
+    # every output whose R contributing raw entries come from agreeing completions (one cascaded tie hides only its own)
+    ok = same.reshape(B, L, R).all(-1)
+    assert ok.mean() >= 0.9
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
     # given_num == L scores the sentence itself, whatever the uniforms
     assert torch.equal(comp[:, L - 1], _t(sent).expand(R, B, L))
 
@@ -302,7 +347,7 @@ def test_sample_wide_shapes_against_oracle(V, E, H, N, L, std):
         if precision == "fp32" and tg._lib.lib().tg_gen_supported(V, E, H) == 1:
             continue  # hidden sizes outside the fp32 kernels' set: GEMM path only
         out = tg.ops.gen_sample(gen, N, L, 1, _t(u), forced=_t(ref), precision=precision).cpu().numpy()
-        assert (out == ref).mean() >= 0.999
+        _cases.check_sample_token_parity(out, ref, u, og, 1)
         free = tg.ops.gen_sample(gen, N, L, 1, _t(u), precision=precision).cpu().numpy()
         assert (free == ref).all(-1).mean() >= 0.97
 
@@ -524,6 +569,44 @@ def test_get_reward_c1_full_vs_oracle(precision):
     rw = raw.cpu().numpy().reshape(R, L, B)
     assert np.all((rw >= 0) & (rw <= 1))
     assert np.array_equal(rw[:, L - 1], np.broadcast_to(rw[0, L - 1], (R, B)))
+    assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
+
+
+_C2_ORACLE = {}   # the oracle's full-size configs[1] call, computed once for both precisions
+
+
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+def test_get_reward_c2_full_vs_oracle(precision):
+    """BASELINE configs[1] -- the headline workload -- at FULL size (V5255 L51 E=H=32 B64 rollout_num 16: 52 224
+    completions, 1 305 600 draws, live dropout p = 0.25 from explicit uniforms) against the oracle (about 7 s on the
+    box's 16 host cores): step-wise token parity with every disagreement a CDF tie, raw rows of agreeing completions
+    and the [B,L] rewards they feed within 1e-4, in both generator precisions."""
+    V, L, B, R = 5255, 51, 64, 16
+    gsd = synth.gen_state(V, 32, 32, seed=0, std=1.0)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=0)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(32, 32, V, L), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V), dsd, DEV).train()
+    sent = synth.tokens(1, (B, L), V)
+    u = synth.uniform01(2, (R, L, L, B))
+    og, od = oracle.Gen(gsd), oracle.Dis(dsd)
+    # dropout uniforms drawn on the device and handed to both sides (R*L*B*F = 90 M values)
+    g = torch.Generator(device=DEV)
+    g.manual_seed(3)
+    du_t = torch.rand(R * L, B, od.F, device=DEV, generator=g)
+    if "o" not in _C2_ORACLE:
+        _C2_ORACLE["o"] = oracle.get_reward(og, od, sent, R, u, dropout_p=0.25, dropout_uniforms=du_t.cpu().numpy())
+    o = _C2_ORACLE["o"]
+    replay = tg.ops.gen_rollout(gen, _t(sent), R, _t(u), forced=_t(o["completions"]), precision=precision).cpu().numpy()
+    _cases.check_token_parity(replay, o["completions"], u, og)
+    ro = tg.ROLLOUT(gen)
+    ro.gen_precision = precision
+    rew, raw, comp = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), dropout_uniforms=du_t, return_parts=True)
+    same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * L, B)
+    assert same.mean() >= 0.98
+    np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
+    ok = same.reshape(B, L, R).all(-1)
+    assert ok.mean() >= 0.75          # an output averages 16 completions: a 1 % row disagreement touches ~15 % of them
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
     assert abs(float(rew.mean()) - float(o["reward"].mean())) < 1e-3
 
 
@@ -819,6 +902,7 @@ def test_leak_reward_c1_shape_full_vs_oracle():
     assert same.mean() >= 0.97
     np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
     ok = same.reshape(B, T, R).all(-1)
+    assert ok.mean() >= 0.9
     np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
     for t in range(T):  # the first given_num tokens are the sentence's
         assert torch.equal(comp[:, t, :, :given[t]], _t(sent)[:, :given[t]].expand(R, B, given[t]))
@@ -848,8 +932,9 @@ def test_leak_reward_edge_shapes_against_oracle(V, E, H, K, L, B, R, step):
     assert tuple(rew.shape) == (B, T)
     same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * T, B)
     np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
-    if same.all():
-        np.testing.assert_allclose(rew.cpu().numpy(), o["reward"], atol=1e-4, rtol=0)
+    ok = same.reshape(B, T, R).all(-1)
+    assert ok.mean() >= 0.9
+    np.testing.assert_allclose(rew.cpu().numpy()[ok], o["reward"][ok], atol=1e-4, rtol=0)
 
 
 @pytest.mark.parametrize("ns,batch", [(1, 1), (1, 64), (5, 64), (64, 64), (130, 64), (7, 3)])
@@ -862,10 +947,16 @@ def test_sample_num_batch_rule_and_edges(ns, batch):
     num_batch = ns // batch + 1 if ns != batch else 1
     N = num_batch * batch
     u = synth.uniform01(61, (L, N))
-    ref = oracle.gen_sample(oracle.Gen(gsd), N, L, 1, u)[:ns]
+    og = oracle.Gen(gsd)
+    ref_all = oracle.gen_sample(og, N, L, 1, u)
+    ref = ref_all[:ns]
     out = tg.generator.sample(gen, ns, batch, 1, uniforms=_t(u))
     assert out.device.type == "cpu" and out.dtype == torch.int64 and tuple(out.shape) == (ns, L)
     assert (out.numpy() == ref).all(-1).mean() >= 0.97 and (out.numpy() == ref).mean() >= 0.99
+    # step-wise under the oracle's own tokens, both arithmetic modes: every disagreement must be a CDF tie
+    for precision in GEN_PRECISIONS:
+        replay = tg.ops.gen_sample(gen, N, L, 1, _t(u), forced=_t(ref_all), precision=precision).cpu().numpy()
+        _cases.check_sample_token_parity(replay, ref_all, u, og, 1)
 
 
 def test_nll_edge_loaders():

@@ -190,3 +190,28 @@ def test_allgather_rows_rejects_what_it_cannot_do():
     assert b"bad arguments" in lib.tg_last_error()
     buf = (ctypes.c_float * 64)()
     assert lib.tg_allgather_rows(buf, 0, 8, ctypes.c_void_p(1), None) == -1
+
+
+def test_bench_starts_its_own_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the form of the driver's N = 1 command) starts
+    its ranks itself through torch.distributed.run, as a child process, and relays rank 0's one JSON line; under a
+    launcher (WORLD_SIZE set) it is a rank.  TG_BENCH_DRYRUN=1: rendezvous and relay only, no GPU work."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["TG_BENCH_DRYRUN"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                       # stdout carries the one JSON line and nothing else
+    rec = json.loads(lines[0])
+    assert rec["dry_run"] is True and rec["n_gpus"] == 2
+    assert b"torch.distributed.run" in p.stderr         # it said what it started
+    # a mismatch between --gpus and the launcher's world size is an error, not a silent single-rank run
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env2,
+                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=240)
+    assert p2.returncode != 0 and b"WORLD_SIZE=1" in p2.stderr

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libtextgan_hip.so")
 MAX_FILTERS = 16
 MAX_OUT = 8
+ABI_VERSION = b"textgan_hip 0.3"   # include/textgan_hip.h; argument lists changed in 0.2 and 0.3
 
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
            "tg_gen_teacher_forced_workspace_bytes", "tg_gen_teacher_forced_ws", "tg_gen_pg_forward_workspace_bytes",
@@ -67,6 +68,9 @@ def lib():
                                "or `make -C textgan-pytorch_amd/csrc`)" % LIB_PATH)
         l = C.CDLL(LIB_PATH)
         l.tg_version.restype = C.c_char_p
+        if ABI_VERSION not in l.tg_version():
+            raise RuntimeError("textgan_hip: %s is %r, this binding needs ABI %s -- rebuild it (make -C "
+                               "textgan-pytorch_amd/csrc)" % (LIB_PATH, l.tg_version(), ABI_VERSION.decode()))
         l.tg_last_error.restype = C.c_char_p
         l.tg_gen_rollout_workspace_bytes.restype = C.c_size_t
         l.tg_gen_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -109,7 +113,7 @@ def lib():
         l.tg_gen_pg_forward_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int]
         l.tg_gen_teacher_forced_workspace_bytes.restype = C.c_size_t
         l.tg_gen_teacher_forced_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
-        l.tg_gen_teacher_forced_ws.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 5 + [C.c_size_t, C.c_void_p]
+        l.tg_gen_teacher_forced_ws.argtypes = [C.c_void_p] * 3 + [C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_size_t, C.c_void_p]
         l.tg_gen_teacher_forced_ws.restype = C.c_int
         l.tg_gen_pg_forward.restype = C.c_int
         l.tg_leak_rollout_workspace_bytes.restype = C.c_size_t

@@ -73,6 +73,7 @@ struct GenArgs {
     float* lse_out;            // [N,L] or null
     float* logits_out;         // [N,L,V] or null
     float* states_out;         // [L+1,N,2,H] or null
+    const float* states_in;    // [N,2,H] or null: (h,c) the teacher-forced pass starts from (null = zeros)
     int need_proj;
     // ---- split-fp16 projection (TG_GEN_SPLIT_F16): W_out as MFMA A fragments in load order, see k_gen_make_frag
     const f32x4* frag;         // [4 waves][NT tiles][5][64 lanes] 16-B pieces
@@ -198,9 +199,10 @@ void k_gen(const GenArgs a) {
         valid = fr < a.N;
         tf_row = valid ? fr : a.N - 1;
         tok = clamp_tok(a.inp[tf_row * L], V);  // ids must be < V; clamped for memory safety
-        if (a.states_out && valid && w == 0) {  // slot 0 = zeros
+        if (a.states_in) state0 = a.states_in + tf_row * 2 * kH;   // a carried (h,c): generator.py:40-51
+        if (a.states_out && valid && w == 0) {  // slot 0 = the initial state (zeros without states_in)
             float* s0 = a.states_out + tf_row * 2 * kH;
-            for (int k = hh * kH; k < hh * kH + kH; ++k) s0[k] = 0.f;
+            for (int k = hh * kH; k < hh * kH + kH; ++k) s0[k] = state0 ? state0[k] : 0.f;
         }
     }
     if (sp == 0) tokbuf[n] = tok;
@@ -1054,9 +1056,10 @@ extern "C" int tg_gen_supported(int V, int E, int H) {
     const bool h_pow2 = H == 32 || H == 64 || H == 128 || H == 256 || H == 512;
     return (h_pow2 && E <= 512) ? 0 : 1;
 }
-extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
-                                     float* logp_out, float* lse_out, float* logits_out, float* states_out,
-                                     void* stream) {
+namespace {
+int teacher_forced_impl(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                        const float* states_in, float* logp_out, float* lse_out, float* logits_out, float* states_out,
+                        void* stream) {
     int rc = check_weights(w);
     if (rc) return rc;
     if (N < 0 || L < 1 || (N > 0 && !inp)) {   // an empty batch (N = 0, any pointers) is a no-op
@@ -1075,8 +1078,16 @@ extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, 
     a.lse_out = lse_out;
     a.logits_out = logits_out;
     a.states_out = states_out;
+    a.states_in = states_in;
     a.need_proj = ((target && logp_out) || lse_out || logits_out) ? 1 : 0;
     return launch<false>(a, (N + kRows - 1) / kRows, (hipStream_t)stream);
+}
+}  // namespace
+
+extern "C" int tg_gen_teacher_forced(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
+                                     float* logp_out, float* lse_out, float* logits_out, float* states_out,
+                                     void* stream) {
+    return teacher_forced_impl(w, inp, target, N, L, nullptr, logp_out, lse_out, logits_out, states_out, stream);
 }
 
 extern "C" size_t tg_gen_teacher_forced_workspace_bytes(const TgGenWeights* w, int N, int L, int have_logits_out,
@@ -1086,15 +1097,19 @@ extern "C" size_t tg_gen_teacher_forced_workspace_bytes(const TgGenWeights* w, i
 }
 
 extern "C" int tg_gen_teacher_forced_ws(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
-                                        float* logp_out, float* lse_out, float* logits_out, float* states_out,
-                                        void* workspace, size_t workspace_bytes, void* stream) {
+                                        const float* states_in, float* logp_out, float* lse_out, float* logits_out,
+                                        float* states_out, void* workspace, size_t workspace_bytes, void* stream) {
     if (!w || !w->emb || !w->w_ih || !w->w_hh || !w->b_ih || !w->b_hh || !w->w_out || !w->b_out) {
         tg_set_error("generator weights: null pointer");
         return TG_ERR_ARG;
     }
     const int sup = tg_gen_supported(w->V, w->E, w->H);
+    if (states_in && ((uintptr_t)states_in & 15)) {
+        tg_set_error("tg_gen_teacher_forced_ws: states_in must be 16-byte aligned");
+        return TG_ERR_ARG;
+    }
     if (sup == 0)
-        return tg_gen_teacher_forced(w, inp, target, N, L, logp_out, lse_out, logits_out, states_out, stream);
+        return teacher_forced_impl(w, inp, target, N, L, states_in, logp_out, lse_out, logits_out, states_out, stream);
     if (sup < 0) return check_weights(w);
     if (N < 0 || L < 1 || (N > 0 && !inp) || (size_t)N * L >= ((size_t)1 << 31) - 256) {
         tg_set_error("tg_gen_teacher_forced_ws: bad arguments (N=%d L=%d)", N, L);
@@ -1102,7 +1117,7 @@ extern "C" int tg_gen_teacher_forced_ws(const TgGenWeights* w, const int64_t* in
     }
     if (N == 0) return TG_OK;
     return tg_pgw_forward(w, inp, target, N, L, logp_out, lse_out, logits_out, states_out, workspace, workspace_bytes,
-                          (hipStream_t)stream);
+                          (hipStream_t)stream, states_in);
 }
 
 extern "C" size_t tg_gen_nll_workspace_bytes(const TgGenWeights* w, int N) {

@@ -11,7 +11,7 @@ bool tg_pgw_shape_ok(const TgGenWeights* w);   // E, H multiples of 32 up to 102
 size_t tg_pgw_forward_workspace_bytes(const TgGenWeights* w, int N, int L, bool have_logits, bool have_states);
 int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L, float* logp_out,
                    float* lse_out, float* logits_out, float* states_out, void* workspace, size_t workspace_bytes,
-                   hipStream_t stream);
+                   hipStream_t stream, const float* states_in = nullptr);   // states_in [N,2,H]: initial (h,c), null = zeros
 size_t tg_pgw_backward_workspace_bytes(const TgGenWeights* w, int N, int L);
 int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, const float* coeff,
                     const float* lse, const float* states, int N, int L, int64_t padding_idx, const TgGenGrads* grads,

@@ -305,7 +305,7 @@ size_t tg_pgw_forward_workspace_bytes(const TgGenWeights* w, int N, int L, bool 
 
 int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L, float* logp_out,
                    float* lse_out, float* logits_out, float* states_out, void* workspace, size_t workspace_bytes,
-                   hipStream_t s) {
+                   hipStream_t s, const float* states_in) {
     const int V = w->V, E = w->E, H = w->H;
     const long NL = (long)N * L;
     const size_t need = tg_pgw_forward_workspace_bytes(w, N, L, logits_out != nullptr, states_out != nullptr);
@@ -321,8 +321,13 @@ int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* tar
     float* states = states_out ? states_out : (float*)ws;
     tg_prof_begin(TG_KERNEL_PGW_FORWARD, s);
     hipLaunchKernelGGL(k_tok_tn, dim3(blocks(NL)), dim3(256), 0, s, inp, N, L, idx);
-    hipLaunchKernelGGL(k_zero, dim3(blocks((long)N * 2 * H) < 1024 ? blocks((long)N * 2 * H) : 1024), dim3(256), 0, s,
-                       states, (long)N * 2 * H);
+    // slot 0: the initial state -- zeros (init_hidden, generator.py:102-109) or the caller's carried (h,c)
+    if (states_in)
+        hipLaunchKernelGGL(k_copy, dim3(blocks((long)N * 2 * H) < 1024 ? blocks((long)N * 2 * H) : 1024), dim3(256), 0, s,
+                           states_in, states, (long)N * 2 * H);
+    else
+        hipLaunchKernelGGL(k_zero, dim3(blocks((long)N * 2 * H) < 1024 ? blocks((long)N * 2 * H) : 1024), dim3(256), 0, s,
+                           states, (long)N * 2 * H);
     for (int t = 0; t < L; ++t) {
         // gates = emb[inp[:, t]] . W_ih^T + h_{t-1} . W_hh^T   (models/generator.py:47-51)
         gemm<false, false>(s, w->emb, E, w->w_ih, E, pre, 4 * H, N, 4 * H, E, nullptr, false, idx + (long)t * N, nullptr, V);

@@ -14,6 +14,8 @@ Sharding is opt-in: a ROLLOUT shards only over the process group it was given
 initialised torch.distributed for something else (a data-parallel trainer that
 feeds different sentences to every rank) keeps the single-rank behaviour.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -27,9 +29,16 @@ def _resolve(group):
 
 
 def _host_staged(g, t):
-    """gloo moves CUDA tensors through its own pinned buffers and streams, which proved unreliable with several ranks
-    on one device (a hung all_gather on the one-GPU test box): with a gloo group the collectives here run on host
-    copies instead.  RCCL ("nccl") groups take the device tensors directly."""
+    """With a gloo group the collectives here run on host copies of CUDA tensors; RCCL ("nccl") groups take the device
+    tensors directly.  Why: in this image (torch 2.10 + ROCm 7.0) ProcessGroupGloo's own CUDA-tensor path stalls for
+    good when a collective is entered while the calling stream still has work in flight.  Established in round 3 with
+    tools/diag/gloo_cuda_repro.py (logs: profiles/r03_gloo_cuda_stall.txt): it needs no product code (torch matmuls in
+    front of all_gather_into_tensor are enough), no second process (a one-rank group stalls too) and no broadcast in
+    front; it does not happen when the device is idle at entry (torch.cuda.synchronize() first: 6 of 6 calls pass),
+    and the same event / side-stream / pinned-copy sequence written by hand in two processes sharing the GPU passes.
+    `.cpu()` below drains the stream and hands gloo host memory, which is the path gloo is built for."""
+    if os.environ.get("TG_DIST_GLOO_DEVICE") == "1":      # diagnosis only (tools/diag/gloo_cuda_repro.py)
+        return False
     return t.is_cuda and dist.get_backend(g) == "gloo"
 
 

@@ -33,16 +33,21 @@ def forward_logprobs(gen, inp):
 
 def forward(gen, inp, hidden=None, need_hidden=False):
     """LSTMGenerator.forward(inp, hidden, need_hidden) (models/generator.py:40-60) under no_grad: ``inp`` [N] (one
-    step, :48-49) or [N,T]; returns log-probabilities [(N*T), V] (row = n*T + t) and, with ``need_hidden``, the new
-    (h, c), each [1,N,H].  ``hidden`` must be None or the zero state of ``init_hidden`` -- what every caller outside
-    the rollout and ``sample`` (both replaced whole) passes; a carried state raises."""
+    step, :48-49) or [N,T]; ``hidden`` None (zeros, init_hidden) or any carried (h, c), each [1,N,H], as the reference
+    accepts; returns log-probabilities [(N*T), V] (row = n*T + t) and, with ``need_hidden``, the new (h, c)."""
     if inp.dim() == 1:
         inp = inp.unsqueeze(1)
-    if hidden is not None and any(bool(torch.count_nonzero(t)) for t in hidden):
-        raise RuntimeError("textgan_hip generator.forward: only the zero initial state is supported (the rollout and "
-                           "sample, which carry a state, are separate entry points)")
+    states_in = None
+    if hidden is not None:
+        h, c = hidden
+        N = inp.shape[0]
+        if h.dim() != 3 or c.dim() != 3 or h.shape[0] != 1 or h.shape[1] != N or tuple(h.shape) != tuple(c.shape):
+            raise RuntimeError("textgan_hip generator.forward: hidden must be (h, c), each [1, %d, H], got %s and %s"
+                               % (N, tuple(h.shape), tuple(c.shape)))
+        states_in = torch.stack([h[0], c[0]], 1).to(device=inp.device, dtype=torch.float32).contiguous()   # [N,2,H]
     with torch.no_grad():
-        r = ops.gen_teacher_forced(gen, inp, want_lse=True, want_logits=True, want_states=need_hidden)
+        r = ops.gen_teacher_forced(gen, inp, want_lse=True, want_logits=True, want_states=need_hidden,
+                                   states_in=states_in)
     N, T, V = r["logits"].shape
     pred = (r["logits"] - r["lse"].unsqueeze(-1)).view(N * T, V)
     if not need_hidden:

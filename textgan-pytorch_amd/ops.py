@@ -47,9 +47,11 @@ def _tokens(t, name):
 
 
 @_on_device
-def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, want_logits=False, want_states=False):
-    """tg_gen_teacher_forced: LSTMGenerator.forward over [N,L] with zero initial state
-    (models/generator.py:40-60).  Returns dict(logp [N,L], lse [N,L], logits [N,L,V], states [L+1,N,2,H])."""
+def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, want_logits=False, want_states=False,
+                       states_in=None):
+    """tg_gen_teacher_forced_ws: LSTMGenerator.forward over [N,L] (models/generator.py:40-60) from the zero state or,
+    with ``states_in`` [N,2,H], from a carried (h, c).  Returns dict(logp [N,L], lse [N,L], logits [N,L,V],
+    states [L+1,N,2,H])."""
     w, keep = _lib.gen_weights(gen, teacher=True)
     inp, _ = _tokens(inp, "inp")
     N, L = inp.shape
@@ -59,13 +61,18 @@ def gen_teacher_forced(gen, inp, target=None, want_logp=True, want_lse=False, wa
     lse = torch.empty(N, L, dtype=F32, device=dev) if want_lse else None
     logits = torch.empty(N, L, w.V, dtype=F32, device=dev) if want_logits else None
     states = torch.empty(L + 1, N, 2, w.H, dtype=F32, device=dev) if want_states else None
+    if states_in is not None:
+        if tuple(states_in.shape) != (N, 2, w.H):
+            raise RuntimeError("textgan_hip: states_in must be [N, 2, H] = [%d, 2, %d], got %s"
+                               % (N, w.H, tuple(states_in.shape)))
+        states_in = states_in.float().contiguous()
     # shapes outside the persistent kernel's set run as fp32 GEMMs and need scratch (0 bytes otherwise)
     nbytes = _lib.lib().tg_gen_teacher_forced_workspace_bytes(C.byref(w), N, L, int(want_logits), int(want_states))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=dev) if nbytes else None
     _lib.check(_lib.lib().tg_gen_teacher_forced_ws(
         C.byref(w), _lib.dev_ptr(inp, I64, "inp"), _lib.dev_ptr(tgt, I64, "target"), N, L,
-        _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(logits), _lib.dev_ptr(states), _lib.dev_ptr(ws), nbytes,
-        _lib.stream_ptr()))
+        _lib.dev_ptr(states_in, F32, "states_in"), _lib.dev_ptr(logp), _lib.dev_ptr(lse), _lib.dev_ptr(logits),
+        _lib.dev_ptr(states), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
     return {"logp": logp, "lse": lse, "logits": logits, "states": states}
 
 

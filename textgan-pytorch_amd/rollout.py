@@ -24,9 +24,12 @@ class ROLLOUT:
     #: dropout masks of the scorer when no dropout_uniforms are passed: "kernel" = counter-based, generated inside the
     #: highway epilogue from a per-call seed (no [N, F] tensor); "torch" = torch.rand uniforms (ROLLOUT.generator)
     dropout_rng = "kernel"
-    #: with a process group: broadcast the generator's and the scorer's weights from rank 0 of the group at the top of
-    #: every get_reward call (once per adversarial step); switch off when the trainer keeps the
-    #: replicas equal by other means (DDP, an explicit tg.dist.sync_weights)
+    #: with a process group: broadcast weights from rank 0 of the group at the top of every get_reward call (once per
+    #: adversarial step).  True / "both": the generator's and the scorer's; "gen" / "dis": that module
+    #: only (SentiGAN's k generators share one D that nobody steps between their calls: the first call of a step
+    #: carries it, the others say "gen"); False: none -- the trainer keeps the replicas equal by other means (DDP, an
+    #: explicit tg.dist.sync_weights).  The value must be the same on every rank of the group: it decides whether a
+    #: collective is entered.
     sync_weights = True
 
     def __init__(self, gen, gpu=True):
@@ -60,19 +63,36 @@ class ROLLOUT:
         if sentences.dim() != 2 or sentences.shape[1] != self.max_seq_len:
             raise RuntimeError("textgan_hip ROLLOUT: sentences must be [batch, %d]" % self.max_seq_len)
 
+    def _sync(self, dis):
+        sel = self.sync_weights
+        if sel is True:
+            sel = "both"
+        if sel not in ("both", "gen", "dis"):
+            raise RuntimeError("textgan_hip ROLLOUT: sync_weights must be True, False, 'both', 'gen' or 'dis', got %r"
+                               % (self.sync_weights,))
+        with self._timed("sync_weights"):
+            tdist.sync_weights(self.gen if sel in ("both", "gen") else None,
+                               dis if sel in ("both", "dis") else None, self.group)
+
     def _rand(self, shape, device, plan=None):
         """U[0,1) draws.  Single rank: ROLLOUT.generator (None = torch's default).  Sharded: every rank holds the same
         torch seed, so each draws from a private generator seeded from (base seed, rank) -- otherwise rank k's
-        completions would be bit-copies of rank 0's and the effective rollout_num R / world."""
+        completions would be bit-copies of rank 0's and the effective rollout_num R / world.  The base seed is
+        ROLLOUT.generator's initial_seed() (torch.initial_seed() without one); the private generator is rebuilt
+        whenever that seed or the generator object changes, so torch.manual_seed / generator.manual_seed re-seed a
+        sharded run as they re-seed a single-rank one (the state of the user's generator itself is not consumed)."""
         gen = self.generator
         if plan is not None and plan.world > 1:
+            base = self.generator.initial_seed() if self.generator is not None else torch.initial_seed()
             key = (str(device), plan.rank)
-            gen = self._rank_gens.get(key)
-            if gen is None:
-                base = self.generator.initial_seed() if self.generator is not None else torch.initial_seed()
+            tag = (id(self.generator), int(base))
+            hit = self._rank_gens.get(key)
+            if hit is None or hit[0] != tag:
                 gen = torch.Generator(device=device)
                 gen.manual_seed(tdist.rank_seed(base, plan.rank))
-                self._rank_gens[key] = gen
+                self._rank_gens[key] = (tag, gen)
+            else:
+                gen = hit[1]
         return torch.rand(shape, dtype=torch.float32, device=device, generator=gen)
 
     # ------------------------------------------------------------------ reference API
@@ -106,8 +126,7 @@ class ROLLOUT:
         Rl = plan.i_hi - plan.i_lo
         with torch.no_grad():
             if plan.world > 1 and self.sync_weights:
-                with self._timed("sync_weights"):
-                    tdist.sync_weights(self.gen, dis, self.group)
+                self._sync(dis)
             if uniforms is None:
                 u = self._rand((Rl, L, L, B), dev, plan)
             else:
@@ -207,8 +226,7 @@ class ROLLOUT:
         Rl = plan.i_hi - plan.i_lo
         with torch.no_grad():
             if plan.world > 1 and self.sync_weights:
-                with self._timed("sync_weights"):
-                    tdist.sync_weights(self.gen, dis, self.group)
+                self._sync(dis)
             if uniforms is None:
                 u = self._rand((Rl, T, L, B), dev, plan)
             else:
