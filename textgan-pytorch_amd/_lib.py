@@ -9,7 +9,8 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtextgan_hip.so")
+# TEXTGAN_HIP_LIB: another build of the same library (diagnostic builds with in-kernel stamps, tools/ubench)
+LIB_PATH = os.environ.get("TEXTGAN_HIP_LIB") or os.path.join(_HERE, "libtextgan_hip.so")
 MAX_FILTERS = 16
 MAX_OUT = 8
 ABI_VERSION = b"textgan_hip 0.3"   # include/textgan_hip.h; argument lists changed in 0.2 and 0.3

@@ -881,6 +881,9 @@ __device__ __forceinline__ void hw_glds16(const void* g, void* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The epilogue's constants -- the highway bias and the output layer's rows of the tile's features -- are staged per
+// tile in LDS behind the two operand stages (two buffers of [1 + n_out][32 MBT] floats, zero past F, written during
+// the tile's first K step): read per quad from L2 each one is a dependent ~1 us round trip with the matrix pipes idle.
 template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_dis_highway_frag(const Hw2Args a) {
@@ -888,7 +891,10 @@ void k_dis_highway_frag(const Hw2Args a) {
     constexpr int MBT = WM * TM, RBT = WN * TN;
     constexpr int NLA = MBT * 256 / NTHR, NLB = RBT * 256 / NTHR;
     constexpr int STAGE = (MBT + RBT) * 256;
+    constexpr int BM = 32 * MBT;
+    constexpr int SPT = ((1 + kMaxOut) * BM + NTHR - 1) / NTHR;   // stash floats per thread, at most
     extern __shared__ __attribute__((aligned(16))) f32x4 hlds[];
+    float* stash0 = reinterpret_cast<float*>(hlds + 2 * STAGE);
     const int tid = threadIdx.x;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
@@ -924,11 +930,22 @@ void k_dis_highway_frag(const Hw2Args a) {
     f32x16 acc[TM][TN];
     load_stage(mb0, rb0, 0, 0);
     __syncthreads();
-    int gs = 0;
-    for (;;) {
+    int gs = 0, tile_no = 0;
+    const int stash_n = (1 + a.h.w.n_out) * BM;   // floats per stash buffer
+    for (;; ++tile_no) {
         int nmb0 = 0, nrb0 = 0;
         const int nlb = next_valid(lb + stride, nmb0, nrb0);
         const bool has_next = nlb < lb_end;
+        float* stash = stash0 + (tile_no & 1) * stash_n;
+        float sv[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {   // row 0: hw_b, row 1 + o: out_w[o]; features 32 mb0 .. + BM - 1
+            const int i = tid + j * NTHR;
+            const int row = i / BM, fidx = 32 * mb0 + (i - row * BM);
+            sv[j] = 0.f;
+            if (i < stash_n && fidx < a.h.w.F)
+                sv[j] = row == 0 ? a.h.w.hw_b[fidx] : a.h.w.out_w[(size_t)(row - 1) * a.h.w.F + fidx];
+        }
 #pragma unroll
         for (int mi = 0; mi < TM; ++mi)
 #pragma unroll
@@ -968,10 +985,20 @@ void k_dis_highway_frag(const Hw2Args a) {
                     for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
                 __builtin_amdgcn_s_setprio(0);
             }
+            if (s == 0) {   // the tile's stash: read by its epilogue, many barriers from here; the other buffer is the
+                            // previous tile's, which slower waves may still be reading
+#pragma unroll
+                for (int j = 0; j < SPT; ++j)
+                    if (tid + j * NTHR < stash_n) stash[tid + j * NTHR] = sv[j];
+            }
             __syncthreads();
         }
 
-        // ---- epilogue of this wave: feature blocks mbw .. mbw+TM-1, sequence blocks rbw .. rbw+TN-1
+        // ---- epilogue of this wave: feature blocks mbw .. mbw+TM-1, sequence blocks rbw .. rbw+TN-1.
+        // Branch-free per quad and software-pipelined over the (sequence block, 64-feature slot) groups: the pooled
+        // halves of group g+1 (global, long evicted from L2 by the K loop's stream) are in flight while group g is
+        // computed; the highway bias and the output layer come from the tile's LDS stash.  The arithmetic and its
+        // order are those of the first version of this kernel: results are bit-identical.
         {
             const int F = a.h.w.F, n_out = a.h.w.n_out;
             const float inv = a.scales[6], invP = a.scales[7];
@@ -979,71 +1006,85 @@ void k_dis_highway_frag(const Hw2Args a) {
             // partial slots are per 64 features whatever the tile shape: shards of a call (other N, maybe the other
             // tile shape) then sum their logits in the same order and stay bit-identical to the unsharded call
             static_assert(TM % 2 == 0, "two feature blocks per partial slot");
+            constexpr int NG = TN * (TM / 2);
+            f16x4 ph[2][8], pl[2][8];
+            auto fetch = [&](int g, f16x4 (&h8)[8], f16x4 (&l8)[8]) {
+                const int ni = g / (TM / 2), sl = g % (TM / 2);
+                const int rb = rbw + ni;
 #pragma unroll
-            for (int ni = 0; ni < TN; ++ni) {
+                for (int it = 0; it < 8; ++it) {
+                    const int mb = mbw + 2 * sl + (it >> 2), rq = it & 3;
+                    // pooled[seq][fb .. fb+3] from the B pieces: k block 2*mb + (rq >> 1), lane n + 32*(rq & 1), half hh
+                    const int kb = tg_min(2 * mb + (rq >> 1), a.KB - 1);   // blocks past F: any piece, the value is dropped
+                    const _Float16* pp = reinterpret_cast<const _Float16*>(a.Pf) +
+                                         ((((size_t)rb * a.KB + kb) * 2) * 64 + n + 32 * (rq & 1)) * 8 + 4 * hh;
+                    h8[it] = *reinterpret_cast<const f16x4*>(pp);
+                    l8[it] = *reinterpret_cast<const f16x4*>(pp + 512);
+                }
+            };
+            auto group = [&](int g, const f16x4 (&h8)[8], const f16x4 (&l8)[8]) {
+                const int ni = g / (TM / 2), sl = g % (TM / 2);
                 const int rb = rbw + ni;
                 const int seq = rb * 32 + n;
+                const bool seq_ok = seq < a.h.N;
+                float part[kMaxOut];
 #pragma unroll
-                for (int sl = 0; sl < TM / 2; ++sl) {
-                    float part[kMaxOut];
+                for (int o = 0; o < kMaxOut; ++o) part[o] = 0.f;
 #pragma unroll
-                    for (int o = 0; o < kMaxOut; ++o) part[o] = 0.f;
+                for (int it = 0; it < 8; ++it) {
+                    const int mi = 2 * sl + (it >> 2), rq = it & 3;
+                    const int fb = 32 * (mbw + mi) + 8 * rq + 4 * hh;   // 4 consecutive features (F % 8 == 0: all in or all out)
+                    const bool f_ok = fb < F;
+                    const int fl = 32 * (TM * wm + mi) + 8 * rq + 4 * hh;   // feature index inside the tile
+                    const f32x4 hb = *reinterpret_cast<const f32x4*>(stash + fl);
+                    float fv[4];
 #pragma unroll
-                    for (int m2 = 0; m2 < 2; ++m2) {
-                        const int mi = 2 * sl + m2;
-                        const int mb = mbw + mi;
+                    for (int e = 0; e < 4; ++e) {
+                        const float pooled = ((float)h8[it][e] + (float)l8[it][e]) * invP;
+                        const float h = __builtin_fmaf(acc[mi][ni][4 * rq + e], inv, hb[e]);
+                        const float sg = tg_sigmoid(h);
+                        fv[e] = sg * __builtin_fmaxf(h, 0.f) + (1.f - sg) * pooled;
+                    }
+                    const size_t o4 = (size_t)seq * F + fb;
+                    if (a.h.feature_out && seq_ok && f_ok)
+                        *reinterpret_cast<f32x4*>(a.h.feature_out + o4) = f32x4{fv[0], fv[1], fv[2], fv[3]};
+                    if (a.h.dropout_u) {
+                        if (seq_ok && f_ok) {
+                            const f32x4 u = *reinterpret_cast<const f32x4*>(a.h.dropout_u + o4);
 #pragma unroll
-                        for (int rq = 0; rq < 4; ++rq) {
-                            const int fb = 32 * mb + 8 * rq + 4 * hh;   // 4 consecutive features (F % 8 == 0: all in or all out)
-                            if (fb >= F) continue;
-                            // pooled[seq][fb .. fb+3] from the B pieces: k block 2*mb + (rq >> 1), lane n + 32*(rq & 1), half hh
-                            const _Float16* pp = reinterpret_cast<const _Float16*>(a.Pf) +
-                                                 ((((size_t)rb * a.KB + 2 * mb + (rq >> 1)) * 2) * 64 + n + 32 * (rq & 1)) * 8 + 4 * hh;
-                            const f16x4 ph = *reinterpret_cast<const f16x4*>(pp);
-                            const f16x4 pl = *reinterpret_cast<const f16x4*>(pp + 512);
-                            const f32x4 hb = *reinterpret_cast<const f32x4*>(a.h.w.hw_b + fb);
-                            float fv[4];
+                            for (int e = 0; e < 4; ++e) fv[e] = (u[e] < a.h.keep) ? fv[e] * a.h.scale : 0.f;
+                        }
+                    } else if (a.h.drop_gen) {
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float pooled = ((float)ph[e] + (float)pl[e]) * invP;
-                                const float h = __builtin_fmaf(acc[mi][ni][4 * rq + e], inv, hb[e]);
-                                const float sg = tg_sigmoid(h);
-                                fv[e] = sg * __builtin_fmaxf(h, 0.f) + (1.f - sg) * pooled;
-                            }
-                            if (seq < a.h.N) {
-                                const size_t o4 = (size_t)seq * F + fb;
-                                if (a.h.feature_out)
-                                    *reinterpret_cast<f32x4*>(a.h.feature_out + o4) = f32x4{fv[0], fv[1], fv[2], fv[3]};
-                                if (a.h.dropout_u) {
-                                    const f32x4 u = *reinterpret_cast<const f32x4*>(a.h.dropout_u + o4);
+                        for (int e = 0; e < 4; ++e)
+                            fv[e] = tg_drop_keep((uint32_t)seq * (uint32_t)F + (uint32_t)(fb + e), a.h.drop_seed, a.h.keep_u32)
+                                        ? fv[e] * a.h.scale : 0.f;
+                    }
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e) fv[e] = (u[e] < a.h.keep) ? fv[e] * a.h.scale : 0.f;
-                                } else if (a.h.drop_gen) {
+                    for (int e = 0; e < 4; ++e) fv[e] = f_ok ? fv[e] : 0.f;   // features past F add nothing
 #pragma unroll
-                                    for (int e = 0; e < 4; ++e)
-                                        fv[e] = tg_drop_keep((uint32_t)seq * (uint32_t)F + (uint32_t)(fb + e), a.h.drop_seed, a.h.keep_u32)
-                                                    ? fv[e] * a.h.scale : 0.f;
-                                }
-                            }
+                    for (int o = 0; o < kMaxOut; ++o) {
+                        if (o < n_out) {
+                            const f32x4 ow = *reinterpret_cast<const f32x4*>(stash + (o + 1) * BM + fl);
 #pragma unroll
-                            for (int o = 0; o < kMaxOut; ++o) {
-                                if (o < n_out) {
-                                    const f32x4 ow = *reinterpret_cast<const f32x4*>(a.h.w.out_w + (size_t)o * F + fb);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) part[o] = __builtin_fmaf(fv[e], ow[e], part[o]);
-                                }
-                            }
+                            for (int e = 0; e < 4; ++e) part[o] = __builtin_fmaf(fv[e], ow[e], part[o]);
                         }
                     }
-#pragma unroll
-                    for (int o = 0; o < kMaxOut; ++o) part[o] += __shfl_xor(part[o], 32, 64);   // the two feature halves of a row
-                    if (hh == 0 && seq < a.h.N) {
-                        float* po = a.h.partial + ((size_t)seq * a.h.nchunk + (mbw >> 1) + sl) * kMaxOut;
-#pragma unroll
-                        for (int o = 0; o < kMaxOut; ++o)
-                            if (o < n_out) po[o] = part[o];
-                    }
                 }
+#pragma unroll
+                for (int o = 0; o < kMaxOut; ++o) part[o] += __shfl_xor(part[o], 32, 64);   // the two feature halves of a row
+                if (hh == 0 && seq_ok) {
+                    float* po = a.h.partial + ((size_t)seq * a.h.nchunk + (mbw >> 1) + sl) * kMaxOut;
+#pragma unroll
+                    for (int o = 0; o < kMaxOut; ++o)
+                        if (o < n_out) po[o] = part[o];
+                }
+            };
+            fetch(0, ph[0], pl[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) fetch(g + 1, ph[(g + 1) & 1], pl[(g + 1) & 1]);
+                group(g, ph[g & 1], pl[g & 1]);
             }
         }
         if (!has_next) break;
@@ -1428,7 +1469,10 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
 template <int WM, int WN, int TM, int TN>
 int launch_highway_frag_t(Hw2Args& a, int MBp, int N, hipStream_t stream) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
-    constexpr size_t sm = (size_t)2 * (WM * TM + WN * TN) * 256 * 16;
+    constexpr size_t sm0 = (size_t)2 * (WM * TM + WN * TN) * 256 * 16;
+    // + two stash buffers of the epilogue's constants ([1 + n_out][BM] floats each): 18 KiB at most beside 128 KiB of
+    // stages (256 x 256 tiles), 9 KiB beside 64 KiB (128 x 128: still two workgroups per CU)
+    const size_t sm = sm0 + (size_t)2 * (1 + a.h.w.n_out) * BM * sizeof(float);
     static TgLdsAttr attr;
     if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_dis_highway_frag<WM, WN, TM, TN>), sm, "k_dis_highway_frag")) return rc;
     a.MT = MBp * 32 / BM;
