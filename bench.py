@@ -212,12 +212,15 @@ def bench_nll(args, dev):
     return out
 
 
-def bench_pg(args, dev):
-    """Side workload pg: the adversarial step's policy-gradient loss, forward + backward, at the
-    real-data generator shape (V5255 L51 E=H=32 B64) -- SeqGAN_G.batchPGLoss + loss.backward() of
-    instructor/real_data/seqgan_instructor.py:109-110 (the optimizer's own update is torch's and is not timed).
-    Beside it, on the same GPU, the reference's formulation in eager torch (nn.LSTM + Linear + log_softmax +
-    one_hot, what models/SeqGAN_G.py:21-39 executes) for the same inputs."""
+def bench_pg(args, dev, wide=False):
+    """Side workloads pg / pgw: the adversarial step's policy-gradient loss, forward + backward --
+    SeqGAN_G.batchPGLoss + loss.backward() of instructor/real_data/seqgan_instructor.py:109-110 (the optimizer's own
+    update is torch's and is not timed) -- at the real-data generator shape (pg: V5255 L51 E=H=32 B64, the fused
+    kernels) or at configs[2]'s generator shape (pgw: V32000 L51 E=H=512 B64, the GEMM formulation, --gen-precision
+    selecting split-fp16 x3 or exact fp32 vocabulary products).  Beside it, on the same GPU, the reference's
+    formulation in eager torch (nn.LSTM + Linear + log_softmax + one_hot, what models/SeqGAN_G.py:21-39 executes)."""
+    if wide:
+        return bench_pgw(args, dev)
     V, L, E, H, B = 5255, 51, 32, 32, 64
     gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=0.1, device=dev)
     gen.name = "seqgan"
@@ -287,6 +290,94 @@ def bench_pg(args, dev):
         out["cpu_baseline"] = {"value": B / t, "unit": "sequences/s", "cores": 1, "kind": "port",
                                "sample": "one full step, numpy restatement (%.2f s; numpy's BLAS may use more "
                                          "threads for the matrix products)" % t}
+    else:
+        out["cpu_baseline"] = None
+    return out
+
+
+def bench_pgw(args, dev):
+    V, L, E, H, B = 32000, 51, 512, 512, 64
+    gen = tg.modules.synthetic_generator(V, E, H, L, seed=0, std=0.05, device=dev)
+    gen.name = "seqgan"
+    target = torch.from_numpy(tg.synth.tokens(31, (B, L), V)).to(dev)
+    inp = torch.cat([torch.ones(B, 1, dtype=torch.int64, device=dev), target[:, :-1]], 1)
+    reward = torch.from_numpy(tg.synth.uniform01(32, (B, L)).astype(np.float32)).to(dev)
+    prec = args.gen_precision or tg._lib.default_gen_precision
+    split = prec == "split_f16"
+
+    def step():
+        loss = tg.pgloss.batchPGLoss(gen, inp, target, reward, precision=prec)
+        gen.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def eager_step():
+        h0 = torch.zeros(1, B, H, device=dev)
+        out, _ = gen.lstm(gen.embeddings(inp), (h0, h0.clone()))
+        logp = torch.log_softmax(gen.lstm2out(out.contiguous().view(-1, H)), -1).view(B, L, V)
+        onehot = torch.nn.functional.one_hot(target, V).float()
+        loss = -torch.sum(torch.sum(logp * onehot, -1) * reward)
+        gen.zero_grad(set_to_none=True)
+        loss.backward()
+        return loss
+
+    def timed(fn, steps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps
+
+    for _ in range(max(args.warmup, 1)):
+        step()
+        eager_step()
+    tg._lib.profile_enable(True)
+    tg._lib.profile_read()
+    dt = timed(step, args.steps)
+    prof = tg._lib.profile_read()
+    tg._lib.profile_enable(False)
+    dt_eager = timed(eager_step, args.steps)
+    per_step = {k: prof[k][0] / args.steps for k in ("pgw_forward", "pgw_backward", "pgw_proj", "pgw_proj_dh", "pgw_proj_dw")}
+    # the vocabulary products: logits (forward), logits again, dlogits . W_out, dlogits^T . h (backward): 4 x 2 H V per row
+    proj_flops = 4 * 2 * H * V * B * L
+    proj_ms = per_step["pgw_proj"] + per_step["pgw_proj_dh"] + per_step["pgw_proj_dw"]
+    ach = proj_flops / (proj_ms * 1e-3) / 1e12
+    one = 2 * H * V * B * L / 1e9   # GFLOP of one product
+    peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+    out = {"metric": "policy-gradient step sequences/sec", "value": B / dt, "unit": "sequences/s", "n_gpus": 1,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (split-f16 x3 operands, f32 accumulate: the vocabulary products)" if split else "f32",
+           "data": "synthetic",
+           "config": {"workload": "batchPGLoss forward + backward at configs[2]'s generator shape: vocab 32000, len 51, "
+                                  "emb/hidden 512, batch 64", "tokens_per_step": B * L},
+           "kernels": {"pgw_forward (states, log-sum-exp rows)": {"ms_per_step": per_step["pgw_forward"]},
+                       "pgw_backward (dlogits, operand fragments, BPTT, weight gradients)": {"ms_per_step": per_step["pgw_backward"]},
+                       "vocabulary products (4 per step)": {"ms_per_step": proj_ms, "tflops": ach},
+                       "logits = h W_out^T + b (2 per step)": {"ms_per_step": per_step["pgw_proj"],
+                                                               "tflops": 2 * one / per_step["pgw_proj"]},
+                       "dh_proj = dlogits W_out": {"ms_per_step": per_step["pgw_proj_dh"], "tflops": one / per_step["pgw_proj_dh"]},
+                       "dW_out = dlogits^T h": {"ms_per_step": per_step["pgw_proj_dw"], "tflops": one / per_step["pgw_proj_dw"]}},
+           "torch_eager_same_gpu": {"ms_per_step": dt_eager * 1e3,
+                                    "what": "nn.LSTM + Linear + log_softmax + one_hot, forward + backward"},
+           "roofline": {"kernel": "pgw_proj", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": ach / peak, "traffic": None, "flops_per_launch": proj_flops / 4,
+                        "avg_launch_ms": proj_ms / 4,
+                        "mfma_products_per_flop": 3 if split else 1, "issued_frac": ach * (3 if split else 1) / peak,
+                        "issued_frac_of_sustained": ach * 3 / SUSTAINED_F16_MFMA_TFLOPS if split else None,
+                        "note": "achieved = 4 products x 2 H V flops per token row / the summed time of their launches"}}
+    if not args.no_cpu_baseline:
+        from oracle import oracle
+        og = oracle.Gen(tg.synth.gen_state(V, E, H, seed=0, std=0.05))
+        nb = 8                                    # a bounded sample: 8 of the 64 sequences
+        a = [x[:nb].cpu().numpy() for x in (inp, target, reward)]
+        t0 = time.perf_counter()
+        oracle.pg_loss_grads(og, *a)
+        t = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": nb / t, "unit": "sequences/s", "cores": 1, "kind": "port",
+                               "sample": "%d of the %d sequences, numpy restatement (%.1f s; numpy's BLAS may use more "
+                                         "threads for the matrix products)" % (nb, B, t)}
     else:
         out["cpu_baseline"] = None
     return out
@@ -519,7 +610,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["c5", "pg", "leak"],
+    ap.add_argument("--workload", default="default", choices=["default"] + sorted(WORKLOADS) + ["c5", "pg", "pgw", "leak"],
                     help="default: the headline line on configs[1] (c2, weak scaling over --gpus) carrying a `scaled` "
                          "sub-record on configs[2]'s shape (c3r8, strong scaling over --gpus); any other name: that "
                          "workload alone")
@@ -581,10 +672,10 @@ def main():
         if world > 1:
             raise SystemExit("workload c5 (NLL) is a single-GPU side measurement")
         return emit(bench_nll(args, dev))
-    if args.workload == "pg":
+    if args.workload in ("pg", "pgw"):
         if world > 1:
-            raise SystemExit("workload pg (policy-gradient step) is a single-GPU side measurement")
-        return emit(bench_pg(args, dev))
+            raise SystemExit("workload %s (policy-gradient step) is a single-GPU side measurement" % args.workload)
+        return emit(bench_pg(args, dev, wide=args.workload == "pgw"))
     if args.workload == "leak":
         if world > 1:
             raise SystemExit("workload leak (LeakGAN rollout) is a single-GPU side measurement")

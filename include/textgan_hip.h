@@ -418,7 +418,10 @@ int tg_allgather_rows(float* raw, size_t rows_per_rank, size_t B, void* rccl_com
 #define TG_KERNEL_LEAK_CELLS 13   /* k_leak_cells                                  */
 #define TG_KERNEL_LEAK_PROJ 14    /* k_leak_proj                                   */
 #define TG_KERNEL_PGW_FORWARD 15  /* GEMM-path teacher-forced forward (tg_pgw.hip, one bracket)  */
-#define TG_KERNEL_PGW_BACKWARD 16 /* GEMM-path policy-gradient backward (tg_pgw.hip, one bracket) */
+#define TG_KERNEL_PGW_BACKWARD 16 /* GEMM-path policy-gradient backward (tg_pgw.hip) without the vocabulary products */
+#define TG_KERNEL_PGW_PROJ 17     /* the GEMM path's logits = h W_out^T + b (forward, and again in the backward): k_fgemm / k_gemm32 */
+#define TG_KERNEL_PGW_PROJ_DH 18  /* dh_proj = dlogits . W_out   */
+#define TG_KERNEL_PGW_PROJ_DW 19  /* dW_out = dlogits^T . h      */
 void tg_profile_enable(int on);
 int tg_profile_read(int kernel_id, double* total_ms, int* count);
 

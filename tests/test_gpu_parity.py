@@ -1154,14 +1154,17 @@ def _grads_of(gen):
     return {k: p.grad.detach().cpu().numpy() for k, p in gen.named_parameters()}
 
 
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
 @pytest.mark.parametrize("name", _cases.names("pg_loss"))
-def test_pg_loss_and_gradients(name):
-    """pgloss.batchPGLoss / adv_loss + .backward() against the reference's loss and .grad (golden) and the oracle."""
+def test_pg_loss_and_gradients(name, precision):
+    """pgloss.batchPGLoss / adv_loss + .backward() against the reference's loss and .grad (golden) and the oracle.
+    precision: beyond E = H = 32 the three vocabulary products run as split-fp16 x3 GEMMs or exact fp32 ones (the fused
+    E = H = 32 kernels are fp32 either way); the same 5e-5 holds in both."""
     c = _cases.load(name)
     sd, inp, target, reward, senti, weight = _cases.pg_inputs(c)
     gen = _pg_gen(c, sd)
     fn = tg.pgloss.adv_loss if str(c["model"]) == "maligan" else tg.pgloss.batchPGLoss
-    loss = fn(gen, _t(inp), _t(target), _t(reward))
+    loss = fn(gen, _t(inp), _t(target), _t(reward), precision=precision)
     gen.zero_grad()
     loss.backward()
     assert loss.item() == pytest.approx(float(c["loss"]), rel=1e-5)
@@ -1197,9 +1200,10 @@ def test_pg_loss_c2_shape_against_oracle():
     assert loss2.item() < loss.item()  # one Adam step on the same batch lowers the loss
 
 
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
 @pytest.mark.parametrize("V,E,H,B,L", [(2, 32, 32, 1, 2), (5, 32, 32, 33, 7), (129, 32, 32, 2, 20), (7, 64, 96, 1, 3),
-                                       (33, 96, 32, 35, 4)])
-def test_pg_loss_edge_shapes_against_oracle(V, E, H, B, L):
+                                       (33, 96, 32, 35, 4), (4099, 64, 64, 9, 5), (515, 32, 128, 70, 6)])
+def test_pg_loss_edge_shapes_against_oracle(V, E, H, B, L, precision):
     """The policy-gradient loss and all seven gradients on the smallest and most ragged batches (one sentence of two
     tokens, a two-word vocabulary, row counts off every tile size), fused kernels (E = H = 32) and GEMM path alike."""
     sd = synth.gen_state(V, E, H, seed=V + L, std=0.3)
@@ -1207,7 +1211,7 @@ def test_pg_loss_edge_shapes_against_oracle(V, E, H, B, L):
     target = synth.tokens(41, (B, L), V)
     inp = np.concatenate([np.zeros((B, 1), np.int64), target[:, :-1]], 1)   # token 0 = padding_idx: its embedding gets no gradient
     reward = synth.uniform01(42, (B, L)).astype(np.float32)
-    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward), precision=precision)
     gen.zero_grad()
     loss.backward()
     oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, reward, padding_idx=0)
@@ -1223,7 +1227,8 @@ def test_pg_loss_rejects_unsupported_shapes_in_forward():
         tg.pgloss.batchPGLoss(gen, t, t, torch.ones(4, 20, device=DEV))
 
 
-def test_pg_loss_wide_shape_against_oracle_and_kernels_used():
+@pytest.mark.parametrize("precision", GEN_PRECISIONS)
+def test_pg_loss_wide_shape_against_oracle_and_kernels_used(precision):
     """A shape with ragged tiles everywhere (V, N*L, E, 4H not multiples of 128; N*L*V > one GEMM tile in every
     dimension) through the GEMM path: loss and gradients against the oracle, the fused E = H = 32 kernels untouched."""
     V, E, H, L, B = 1531, 96, 160, 9, 37
@@ -1234,15 +1239,43 @@ def test_pg_loss_wide_shape_against_oracle_and_kernels_used():
     reward = synth.uniform01(43, (B, L)).astype(np.float32)
     tg._lib.profile_enable(True)
     tg._lib.profile_read()
-    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+    loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward), precision=precision)
     gen.zero_grad()
     loss.backward()
     prof = tg._lib.profile_read()
     tg._lib.profile_enable(False)
-    assert prof["pgw_forward"][1] == 1 and prof["pgw_backward"][1] == 1 and prof["pg_backward"][1] == 0
+    # the vocabulary products carry their own profile id: logits (forward), logits again + dh_proj + dW_out (backward)
+    assert prof["pgw_forward"][1] >= 1 and prof["pgw_backward"][1] >= 1 and prof["pg_backward"][1] == 0
+    assert prof["pgw_proj"][1] == 2 and prof["pgw_proj_dh"][1] == 1 and prof["pgw_proj_dw"][1] == 1
     oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, reward, padding_idx=0)
     assert loss.item() == pytest.approx(oloss, rel=1e-5)
     _cases.assert_grads_close(_grads_of(gen), ograds, rel=5e-5, what="wide")
+
+
+def test_pg_loss_split_across_logit_chunks_against_oracle():
+    """The GEMM path keeps at most 1 GiB of logits alive: V 32 000 with 10 200 token rows is two chunks (8 192 + 2 008
+    rows), so dW_out and db_out accumulate over chunks and dh_proj is cut over k (32 000) into slices summed in order.
+    Loss and all seven gradients against the oracle in the default split-fp16 mode; a second call is bit-identical
+    but for the embedding gradient (float atomics)."""
+    V, E, H, L, B = 32000, 32, 64, 51, 200
+    sd = synth.gen_state(V, E, H, seed=43, std=0.1)
+    gen = tg.modules.load_numpy_state(tg.modules.LSTMGenerator(E, H, V, L, name="seqgan"), sd, DEV)
+    target = synth.tokens(44, (B, L), V)
+    inp = np.concatenate([np.ones((B, 1), np.int64), target[:, :-1]], 1)
+    reward = synth.uniform01(45, (B, L)).astype(np.float32)
+    runs = []
+    for _ in range(2):
+        loss = tg.pgloss.batchPGLoss(gen, _t(inp), _t(target), _t(reward))
+        gen.zero_grad()
+        loss.backward()
+        runs.append((loss.item(), {k: p.grad.detach().clone() for k, p in gen.named_parameters()}))
+    assert runs[0][0] == runs[1][0]
+    for k in _cases.PG_KEYS:
+        if k != "embeddings.weight":
+            assert torch.equal(runs[0][1][k], runs[1][1][k]), k
+    oloss, ograds = oracle.pg_loss_grads(oracle.Gen(sd), inp, target, reward, padding_idx=0)
+    assert runs[0][0] == pytest.approx(oloss, rel=1e-5)
+    _cases.assert_grads_close({k: v.cpu().numpy() for k, v in runs[0][1].items()}, ograds, rel=5e-5, what="two chunks")
 
 
 @pytest.mark.parametrize("V,E,H,N,L,std", [(900, 96, 160, 33, 5, 0.2), (600, 32, 768, 5, 5, 0.05), (333, 64, 96, 130, 7, 0.3)])

@@ -28,7 +28,8 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
 
 KERNELS = {"gen_teacher": 0, "gen_sample": 1, "dis_conv": 2, "dis_highway": 3, "dis_final": 4, "reduce": 5,
            "dis_prefix": 6, "pg_backward": 7, "pg_forward": 8, "genw_cell": 9, "genw_proj": 10, "genw_draw": 11,
-           "leak_draw": 12, "leak_cells": 13, "leak_proj": 14, "pgw_forward": 15, "pgw_backward": 16}
+           "leak_draw": 12, "leak_cells": 13, "leak_proj": 14, "pgw_forward": 15, "pgw_backward": 16, "pgw_proj": 17, "pgw_proj_dh": 18,
+           "pgw_proj_dw": 19}
 
 
 class GenW(C.Structure):

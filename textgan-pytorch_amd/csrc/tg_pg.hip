@@ -537,10 +537,13 @@ bool shape_ok(const TgGenWeights* w, int N, int L) {
 }  // namespace
 
 static bool pg_wide(const TgGenWeights* w) { return w && !(w->E == kHid && w->H == kHid) && tg_pgw_shape_ok(w); }
+// beyond E = H = 32, w->precision selects the arithmetic of the three vocabulary products (TG_GEN_SPLIT_F16: split-fp16
+// GEMMs, TG_GEN_FP32: exact fp32 MFMA); everything else is fp32 in both
+static bool pg_split(const TgGenWeights* w) { return w->precision == TG_GEN_SPLIT_F16; }
 
 extern "C" size_t tg_gen_pg_forward_workspace_bytes(const TgGenWeights* w, int N, int L) {
     if (!pg_wide(w) || N < 1 || L < 1) return 0;
-    return tg_pgw_forward_workspace_bytes(w, N, L, false, true);
+    return tg_pgw_forward_workspace_bytes(w, N, L, false, true, pg_split(w));
 }
 
 extern "C" int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L,
@@ -554,7 +557,7 @@ extern "C" int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp, cons
         }
         if (N == 0) return TG_OK;
         return tg_pgw_forward(w, inp, target, N, L, logp_out, lse_out, nullptr, states_out, workspace, workspace_bytes,
-                              (hipStream_t)stream);
+                              (hipStream_t)stream, nullptr, pg_split(w));
     }
     if (!w || w->E != kHid || w->H != kHid) {
         tg_set_error("tg_gen_pg_forward: generator shape not supported (E, H multiples of 32 up to 1024)");
@@ -577,7 +580,7 @@ extern "C" int tg_gen_pg_forward(const TgGenWeights* w, const int64_t* inp, cons
 }
 
 extern "C" size_t tg_gen_pg_backward_workspace_bytes(const TgGenWeights* w, int N, int L) {
-    if (pg_wide(w) && N >= 1 && L >= 1) return tg_pgw_backward_workspace_bytes(w, N, L);
+    if (pg_wide(w) && N >= 1 && L >= 1) return tg_pgw_backward_workspace_bytes(w, N, L, pg_split(w));
     if (!shape_ok(w, N, L)) return 0;
     return make_layout(w->V, N, L).total;
 }
@@ -598,7 +601,7 @@ extern "C" int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp, con
             return TG_ERR_ARG;
         }
         return tg_pgw_backward(w, inp, target, coeff, lse, states, N, L, padding_idx, grads, workspace, workspace_bytes,
-                               (hipStream_t)stream);
+                               (hipStream_t)stream, pg_split(w));
     }
     if (w->E != kHid || w->H != kHid) {
         tg_set_error("tg_gen_pg_backward: generator shape E=%d H=%d not supported (multiples of 32 up to 1024)", w->E, w->H);

@@ -146,27 +146,150 @@ __global__ __launch_bounds__(256) void k_tok_tn(const int64_t* inp, int N, int L
     idx[r] = inp[(long)n * L + t];
 }
 
-// nn.LSTM cell (gates i,f,g,o): pre [N,4H] (no bias) + b_ih + b_hh, state (h,c) of slot t -> slot t+1 of
-// states [L+1,N,2,H]
-__global__ __launch_bounds__(256) void k_cell_fwd(const float* pre, const float* b_ih, const float* b_hh, float* states,
-                                                   int N, int H, int t) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= (long)N * H) return;
-    const int n = (int)(q / H), u = (int)(q % H);
-    const float* g = pre + (long)n * 4 * H;
-    const float ig = tg_sigmoid(g[u] + (b_ih[u] + b_hh[u]));
-    const float fg = tg_sigmoid(g[H + u] + (b_ih[H + u] + b_hh[H + u]));
-    const float gg = tg_tanh(g[2 * H + u] + (b_ih[2 * H + u] + b_hh[2 * H + u]));
-    const float og = tg_sigmoid(g[3 * H + u] + (b_ih[3 * H + u] + b_hh[3 * H + u]));
-    const float* prev = states + ((long)t * N + n) * 2 * H;
-    float* cur = states + ((long)(t + 1) * N + n) * 2 * H;
-    const float cn = fg * prev[H + u] + ig * gg;
-    cur[H + u] = cn;
-    cur[u] = og * tg_tanh(cn);
-}
-
 __global__ __launch_bounds__(256) void k_zero(float* p, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = 0.f;
+}
+
+
+// ---- the recurrence, one launch per position ------------------------------------------------------------------
+// An adversarial batch is 64 sequences: a [64 x 4H x H] product per position on 128 x 128 GEMM tiles is 16 workgroups
+// each walking K behind two barriers per 32 -- ~40 us per launch, three launches per position, and the whole step was
+// launch latency (27 of 29 ms at E = H = 512).  Here the input side of every position is one batched GEMM
+// (X W_ih^T, in the backward also H_prev W_hh^T: all h_{t-1} are known there), and a position costs ONE launch:
+// workgroup (unit tile of 32, row tile of 32), 8 waves, each wave one slice of the contraction with all its operand
+// loads in flight at once (16-byte loads straight from L2: a lane's 16 consecutive k of its row, the MFMA's k order
+// being free as long as A and B agree), partial tiles summed through LDS in wave order, then the element-wise part
+// with threads remapped so that consecutive threads own consecutive units (coalesced state / gradient rows).
+constexpr int kStepThreads = 512;
+constexpr int kPartLd = 33;
+
+// acc += A[row_a][k] . B[row_b][k] over chunks [c0, c1) of 32 k: lane (i = lane & 31, hh = lane >> 5) feeds k = 32 c +
+// 16 hh + q, q = 0..15, to the q-th MFMA on both operands
+__device__ __forceinline__ void step_dot(f32x16& acc, const float* __restrict__ arow, const float* __restrict__ brow, int hh,
+                                         int c0, int c1) {
+    for (int c = c0; c < c1; c += 4) {
+        f32x4 av[4][4], bv[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int cc = c + j < c1 ? c + j : c1 - 1;
+            const f32x4* pa = reinterpret_cast<const f32x4*>(arow + 32 * cc + 16 * hh);
+            const f32x4* pb = reinterpret_cast<const f32x4*>(brow + 32 * cc + 16 * hh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { av[j][q] = pa[q]; bv[j][q] = pb[q]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (c + j < c1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = TG_MFMA32(av[j][q][e], bv[j][q][e], acc);
+            }
+        }
+    }
+}
+
+// Forward position t: gates = preX[t] + b_ih + b_hh + h_{t-1} W_hh^T, cell -> states[t+1]   (models/generator.py:51)
+// wave w: gate w & 3, k half w >> 2.  preX [L*N, 4H] (row t*N + n), states [L+1, N, 2, H].
+__global__ __launch_bounds__(kStepThreads) void k_lstm_step_fwd(const float* __restrict__ preX, const float* __restrict__ w_hh,
+                                                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                                float* __restrict__ states, int N, int H, int t) {
+    __shared__ float part[8][32][kPartLd];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, hh = lane >> 5;
+    const int u0 = 32 * blockIdx.x, n0 = 32 * blockIdx.y;
+    const int g = w & 3, kh = w >> 2;
+    const int nc = H >> 5, half = (nc + 1) >> 1;
+    const int nrow = n0 + i < N ? n0 + i : N - 1;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    step_dot(acc, w_hh + (size_t)(g * H + u0 + i) * H, states + ((size_t)t * N + nrow) * 2 * H, hh,
+             kh ? half : 0, kh ? nc : half);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = tid + kStepThreads * q, u = p & 31, nl = p >> 5, n = n0 + nl;
+        if (n >= N) continue;
+        const size_t row = (size_t)t * N + n;
+        float gate[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) {
+            const int col = gg * H + u0 + u;
+            gate[gg] = (part[gg][u][nl] + part[4 + gg][u][nl]) + preX[row * 4 * H + col] + (b_ih[col] + b_hh[col]);
+        }
+        const float ig = tg_sigmoid(gate[0]), fg = tg_sigmoid(gate[1]), gc = tg_tanh(gate[2]), og = tg_sigmoid(gate[3]);
+        const float* prev = states + row * 2 * H;
+        float* cur = states + ((size_t)(t + 1) * N + n) * 2 * H;
+        const float cn = fg * prev[H + u0 + u] + ig * gc;
+        cur[H + u0 + u] = cn;
+        cur[u0 + u] = og * tg_tanh(cn);
+    }
+}
+
+// Backward position t: dh = dhproj[t] + da_{t+1} W_hh, then the cell's gate gradients da_t -> DA[t], dc carried in dcn.
+// P [L*N, 4H]: pre-activations without bias (X W_ih^T + H_prev W_hh^T); w_hhT [H, 4H]; wave w: k slice w of 8.
+__global__ __launch_bounds__(kStepThreads) void k_lstm_step_bwd(const float* __restrict__ P, const float* __restrict__ w_hhT,
+                                                                const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                                const float* __restrict__ states, const float* __restrict__ dhproj,
+                                                                float* __restrict__ dcn, float* __restrict__ DA, int N, int H,
+                                                                int t, int last) {
+    __shared__ float part[8][32][kPartLd];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, hh = lane >> 5;
+    const int u0 = 32 * blockIdx.x, n0 = 32 * blockIdx.y;
+    if (!last) {
+        const int nc = (4 * H) >> 5;                    // a multiple of 4
+        const int c0 = (int)((long)nc * w / 8), c1 = (int)((long)nc * (w + 1) / 8);
+        const int nrow = n0 + i < N ? n0 + i : N - 1;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        step_dot(acc, w_hhT + (size_t)(u0 + i) * 4 * H, DA + ((size_t)(t + 1) * N + nrow) * 4 * H, hh, c0, c1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
+        __syncthreads();
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int p = tid + kStepThreads * q, u = p & 31, nl = p >> 5, n = n0 + nl;
+        if (n >= N) continue;
+        const size_t row = (size_t)t * N + n;
+        const int uu = u0 + u;
+        float dh = dhproj[row * H + uu];
+        if (!last) {
+            float sdot = part[0][u][nl];
+#pragma unroll
+            for (int ww = 1; ww < 8; ++ww) sdot += part[ww][u][nl];
+            dh += sdot;
+        }
+        const float* gp = P + row * 4 * H;
+        const float ig = tg_sigmoid(gp[uu] + (b_ih[uu] + b_hh[uu]));
+        const float fg = tg_sigmoid(gp[H + uu] + (b_ih[H + uu] + b_hh[H + uu]));
+        const float gg = tg_tanh(gp[2 * H + uu] + (b_ih[2 * H + uu] + b_hh[2 * H + uu]));
+        const float og = tg_sigmoid(gp[3 * H + uu] + (b_ih[3 * H + uu] + b_hh[3 * H + uu]));
+        const float cprev = states[row * 2 * H + H + uu];
+        const float ct = states[((size_t)(t + 1) * N + n) * 2 * H + H + uu];
+        const float tc = tg_tanh(ct);
+        const float dc = (last ? 0.f : dcn[(size_t)n * H + uu]) + dh * og * (1.f - tc * tc);
+        float* da = DA + row * 4 * H;
+        da[uu] = dc * gg * ig * (1.f - ig);
+        da[H + uu] = dc * cprev * fg * (1.f - fg);
+        da[2 * H + uu] = dc * ig * (1.f - gg * gg);
+        da[3 * H + uu] = dh * tc * og * (1.f - og);
+        dcn[(size_t)n * H + uu] = dc * fg;
+    }
+}
+
+// dst[c][r] = src[r][c]  (W_hh [4H, H] -> [H, 4H], once per backward call)
+__global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ src, int R, int Cn, float* __restrict__ dst) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8)
+        if (r0 + j < R && c0 + tx < Cn) tile[j][tx] = src[(size_t)(r0 + j) * Cn + c0 + tx];
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8)
+        if (c0 + j < Cn && r0 + tx < R) dst[(size_t)(c0 + j) * R + r0 + tx] = tile[tx][j];
 }
 
 // one workgroup per row r = t*N + n of a logits chunk [rows, ldl]: lse (fp64 merge of per-thread (max, sum) pairs in a
@@ -217,42 +340,6 @@ __global__ __launch_bounds__(256) void k_row_softmax(float* logits, long ldl, in
     }
 }
 
-// out[n] (+)= sum_r X[r*ld + n]: one thread per column, rows split over gridDim.y partial sums are avoided by
-// keeping the row loop whole (fixed order; columns are coalesced across the lanes)
-__global__ __launch_bounds__(256) void k_colsum(const float* X, long ld, long rows, int ncol, float* out, int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= ncol) return;
-    float s = 0.f;
-    for (long r = 0; r < rows; ++r) s += X[r * ld + c];
-    out[c] = accumulate ? out[c] + s : s;
-}
-
-// one BPTT step, element-wise part: pre [N,4H] (recomputed, no bias); states slots t (previous) and t+1 (this
-// step's); dh = dhproj[t*N + n] + dhn[n]; writes DA[t*N + n][4H], dcn <- dc * f.
-__global__ __launch_bounds__(256) void k_bptt_elem(const float* pre, const float* b_ih, const float* b_hh,
-                                                    const float* states, const float* dhproj, const float* dhn, float* dcn,
-                                                    float* DA, int N, int H, int t, int last) {
-    const long q = (long)blockIdx.x * 256 + threadIdx.x;
-    if (q >= (long)N * H) return;
-    const int n = (int)(q / H), u = (int)(q % H);
-    const float* g = pre + (long)n * 4 * H;
-    const float ig = tg_sigmoid(g[u] + (b_ih[u] + b_hh[u]));
-    const float fg = tg_sigmoid(g[H + u] + (b_ih[H + u] + b_hh[H + u]));
-    const float gg = tg_tanh(g[2 * H + u] + (b_ih[2 * H + u] + b_hh[2 * H + u]));
-    const float og = tg_sigmoid(g[3 * H + u] + (b_ih[3 * H + u] + b_hh[3 * H + u]));
-    const float cprev = states[((long)t * N + n) * 2 * H + H + u];
-    const float ct = states[((long)(t + 1) * N + n) * 2 * H + H + u];
-    const float tc = tg_tanh(ct);
-    const float dh = dhproj[((long)t * N + n) * H + u] + (last ? 0.f : dhn[(long)n * H + u]);
-    const float dc = (last ? 0.f : dcn[(long)n * H + u]) + dh * og * (1.f - tc * tc);
-    float* da = DA + ((long)t * N + n) * 4 * H;
-    da[u] = dc * gg * ig * (1.f - ig);
-    da[H + u] = dc * cprev * fg * (1.f - fg);
-    da[2 * H + u] = dc * ig * (1.f - gg * gg);
-    da[3 * H + u] = dh * tc * og * (1.f - og);
-    dcn[(long)n * H + u] = dc * fg;
-}
-
 // d(emb)[tok[r]][e] += dX[r][e] (float atomics, as torch's embedding backward on a GPU); the padding_idx row stays 0
 __global__ __launch_bounds__(256) void k_scatter_emb(const float* dX, const int64_t* idx, long rows, int E, int V,
                                                       int64_t padding_idx, float* demb) {
@@ -267,6 +354,281 @@ __global__ __launch_bounds__(256) void k_scatter_emb(const float* dX, const int6
 
 __global__ __launch_bounds__(256) void k_copy(const float* src, float* dst, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+
+// ============================================================================================================
+// Split-fp16 GEMMs for the three vocabulary products of the policy-gradient step (TG_GEN_SPLIT_F16):
+//   logits = h W_out^T + b,   dh_proj = dlogits W_out,   dW_out = dlogits^T h
+// -- 8 H V flops per token row, everything else in this file is noise beside them at V = 32 000.  Operands are scaled by
+// a per-tensor power of two and written as (hi, lo) fp16 halves IN MFMA FRAGMENT ORDER (k_to_frag: piece
+// ((rb*KB + kb)*2 + part)*64 + lane = 8 halves of row 32 rb + lane%32, k = 16 kb + 8 (lane/32) + 0..7), so the GEMM
+// stages them with LDS-DMA as they lie and every ds_read_b128 is a conflict-free 1-KiB row: the structure of the
+// scorer's highway GEMM (tg_dis.hip) and of the generator's vocabulary GEMM (tg_genw.hip).  A product is
+// hi.hi + hi.lo + lo.hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (22 mantissa bits per operand).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+#define TG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ void fg_glds16(const void* g, void* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+// X (element (r, k) at X[r*rs + k*cs]) -> pieces [RBp][KB][hi|lo][64] x 8 halves of X * scale[si]; zero outside R x K.
+// cs == 1: a lane reads 32 contiguous bytes; rs == 1 (a transposed view): the 32 rows of a piece are contiguous, so
+// each of the 8 loads of a lane is one coalesced segment across the wave.
+__global__ __launch_bounds__(256) void k_to_frag(const float* __restrict__ X, long rs, long cs, int R, int K,
+                                                  const float* __restrict__ scale, int si, int RBp, int KB,
+                                                  f16x8* __restrict__ dst) {
+    const float sc = scale[si];
+    const long total = (long)RBp * KB * 64;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int lane = (int)(i & 63);
+        const long q = i >> 6;
+        const int kb = (int)(q % KB);
+        const long rb = q / KB;
+        const long r = 32 * rb + (lane & 31);
+        const int k0 = 16 * kb + 8 * (lane >> 5);
+        f16x8 h = {0, 0, 0, 0, 0, 0, 0, 0}, l = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (r < R && k0 < K) {
+            const float* p = X + r * rs + (long)k0 * cs;
+            float v[8];
+            if (cs == 1 && k0 + 8 <= K && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = a[e]; v[4 + e] = b[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (k0 + e < K) ? p[(long)e * cs] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float x = v[e] * sc;
+                const _Float16 hh = (_Float16)x;
+                h[e] = hh;
+                l[e] = (_Float16)(x - (float)hh);
+            }
+        }
+        dst[(q * 2) * 64 + lane] = h;
+        dst[(q * 2 + 1) * 64 + lane] = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_absmax_u(const float* x, size_t n, unsigned* out) {
+    __shared__ unsigned red[4];
+    unsigned m = 0;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);   // |x| as ordered bits
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = max(max(red[0], red[1]), max(red[2], red[3]));
+        if (m) atomicMax(out, m);
+    }
+}
+
+// scal: [0] sW (W_out), [1] sH = 2^14 (|h| < 1), [2] 1/(sW sH), [3] sD (dlogits: |d| <= max |coeff|), [4] 1/(sD sW),
+// [5] 1/(sD sH); absmax[0] = |max| W_out, absmax[1] = |max| coeff (0 in the forward)
+__global__ void k_pgw_scales(const unsigned* absmax, float* scal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    auto pow2_for = [](float m) {
+        int ex = 0;
+        float sc = 1.f;
+        if (m > 0.f && m < __builtin_inff()) {
+            (void)frexpf(m, &ex);          // m < 2^ex
+            sc = ldexpf(1.f, 14 - ex);     // m * scale in [2^13, 2^14)
+        }
+        return sc;
+    };
+    const float sW = pow2_for(__uint_as_float(absmax[0])), sH = 16384.f, sD = pow2_for(__uint_as_float(absmax[1]));
+    scal[0] = sW; scal[1] = sH; scal[2] = 1.f / (sW * sH);
+    scal[3] = sD; scal[4] = 1.f / (sD * sW); scal[5] = 1.f / (sD * sH);
+}
+
+// out[n*ldo + m] (+)= inv * sum_k A(m,k) B(n,k) (+ bias[m]); A pieces [MBp][KB][2][64], B pieces [RBp][KB][2][64].
+// Persistent workgroups, XCD-aware tile walk (the 8 workgroups of a group of 8 logical ids share an A tile and take 8
+// row tiles: 8 consecutive ids go to the 8 XCDs, so ids that share an XCD walk the same row tiles), two LDS stages of
+// one k step (32) filled by LDS-DMA, one barrier per step.  nz > 1: the k steps are cut into nz slices, slice z
+// writes out + z*zstride (summed afterwards in fixed order by k_sum_slices).
+struct FgArgs {
+    const f32x4* Af; const f32x4* Bf;
+    int KB, MT, RT, NB, nz, gx;
+    float* out; long ldo, zstride;
+    int M, N, vec, accumulate;
+    const float* scal; int inv_idx;
+    const float* bias;
+};
+
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_fgemm(const FgArgs a) {
+    constexpr int NTHR = 64 * WM * WN;
+    constexpr int MBT = WM * TM, RBT = WN * TN;
+    constexpr int NLA = MBT * 256 / NTHR, NLB = RBT * 256 / NTHR;
+    constexpr int STAGE = (MBT + RBT) * 256;
+    extern __shared__ __attribute__((aligned(16))) f32x4 flds[];
+    const int tid = threadIdx.x;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63, n = lane & 31, hh = lane >> 5;
+    const int wm = w / WN, wn = w % WN;
+    const int z = (int)blockIdx.x / a.gx, bx = (int)blockIdx.x % a.gx;
+    const int per_xcd = a.NB >> 3, stride = a.gx >> 3;
+    const int lb_end = (bx & 7) * per_xcd + per_xcd;
+    const int per = 8 * a.MT;
+    auto decode = [&](int lb, int& mb0, int& rb0) {
+        const int rtg = lb / per, rem = lb - rtg * per;
+        const int rt = rtg * 8 + (rem & 7);
+        mb0 = MBT * (rem >> 3);
+        rb0 = RBT * rt;
+        return rt < a.RT;
+    };
+    auto next_valid = [&](int lb, int& mb0, int& rb0) {
+        while (lb < lb_end && !decode(lb, mb0, rb0)) lb += stride;
+        return lb;
+    };
+    int mb0 = 0, rb0 = 0;
+    int lb = next_valid((bx & 7) * per_xcd + (bx >> 3), mb0, rb0);
+    if (lb >= lb_end) return;
+    const int S = a.KB >> 1;
+    const int s_lo = (int)((long)S * z / a.nz), s_hi = (int)((long)S * (z + 1) / a.nz);
+    if (s_lo >= s_hi) return;
+    const int pw = tid & 255;
+    auto load_stage = [&](int mb, int rb, int s, int buf) {
+        f32x4* d = flds + buf * STAGE + tid;
+#pragma unroll
+        for (int i = 0; i < NLA; ++i)
+            fg_glds16(a.Af + ((size_t)(mb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw, d + i * NTHR);
+#pragma unroll
+        for (int i = 0; i < NLB; ++i)
+            fg_glds16(a.Bf + ((size_t)(rb + ((tid + i * NTHR) >> 8)) * a.KB + 2 * s) * 128 + pw, d + MBT * 256 + i * NTHR);
+    };
+    f32x16 acc[TM][TN];
+    load_stage(mb0, rb0, s_lo, 0);
+    __syncthreads();
+    int gs = 0;
+    float* outz = a.out + (size_t)z * a.zstride;
+    for (;;) {
+        int nmb0 = 0, nrb0 = 0;
+        const int nlb = next_valid(lb + stride, nmb0, nrb0);
+        const bool has_next = nlb < lb_end;
+#pragma unroll
+        for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        for (int s = s_lo; s < s_hi; ++s, ++gs) {
+            if (s + 1 < s_hi) load_stage(mb0, rb0, s + 1, (gs + 1) & 1);
+            else if (has_next) load_stage(nmb0, nrb0, s_lo, (gs + 1) & 1);
+            const f32x4* la = flds + (gs & 1) * STAGE + (TM * wm) * 256 + lane;
+            const f32x4* lbp = flds + (gs & 1) * STAGE + MBT * 256 + (TN * wn) * 256 + lane;
+#pragma unroll
+            for (int kbl = 0; kbl < 2; ++kbl) {
+                f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    bh[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128]);
+                    bl[i] = __builtin_bit_cast(f16x8, lbp[i * 256 + kbl * 128 + 64]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    ah[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128]);
+                    al[i] = __builtin_bit_cast(f16x8, la[i * 256 + kbl * 128 + 64]);
+                }
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(al[mi], bh[ni], acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bl[ni], acc[mi][ni]);
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < TN; ++ni) acc[mi][ni] = TG_MFMA16(ah[mi], bh[ni], acc[mi][ni]);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            __syncthreads();
+        }
+        // ---- epilogue: D reg r of lane (n, hh) -> m = 32 mb + (r&3) + 8 (r>>2) + 4 hh, row 32 rb + n
+        {
+            const float inv = a.scal[a.inv_idx];
+            const int mbw = mb0 + TM * wm, rbw = rb0 + TN * wn;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int row = 32 * (rbw + ni) + n;
+                if (row >= a.N) continue;
+                float* orow = outz + (size_t)row * a.ldo;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int rq = 0; rq < 4; ++rq) {
+                        const int m = 32 * (mbw + mi) + 8 * rq + 4 * hh;
+                        if (m >= a.M) continue;
+                        if (a.vec && m + 3 < a.M) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[e] = acc[mi][ni][4 * rq + e] * inv;
+                            if (a.bias) {
+                                const f32x4 b = *reinterpret_cast<const f32x4*>(a.bias + m);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += b[e];
+                            }
+                            f32x4* d = reinterpret_cast<f32x4*>(orow + m);
+                            if (a.accumulate) {
+                                const f32x4 o = *d;
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += o[e];
+                            }
+                            *d = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (m + e < a.M) {
+                                    float v = acc[mi][ni][4 * rq + e] * inv + (a.bias ? a.bias[m + e] : 0.f);
+                                    if (a.accumulate) v += orow[m + e];
+                                    orow[m + e] = v;
+                                }
+                        }
+                    }
+            }
+        }
+        if (!has_next) break;
+        lb = nlb;
+        mb0 = nmb0;
+        rb0 = nrb0;
+    }
+}
+
+// out[i] = sum_z part[z*zstride + i], z ascending (fixed order)
+__global__ __launch_bounds__(256) void k_sum_slices(const float* part, int nz, long zstride, long n, float* out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float s = part[i];
+        for (int z = 1; z < nz; ++z) s += part[(long)z * zstride + i];
+        out[i] = s;
+    }
+}
+
+// column sums in two deterministic passes: slab y of kSlab rows -> part[y][c]; then the slabs in order
+constexpr int kSlab = 256;
+__global__ __launch_bounds__(256) void k_colsum_slab(const float* X, long ld, long rows, int ncol, float* part) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncol) return;
+    const long r0 = (long)blockIdx.y * kSlab, r1 = r0 + kSlab < rows ? r0 + kSlab : rows;
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += X[r * ld + c];
+    part[(long)blockIdx.y * ncol + c] = s;
+}
+__global__ __launch_bounds__(256) void k_colsum_final(const float* part, int nslab, int ncol, float* out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ncol) return;
+    float s = 0.f;
+    for (int y = 0; y < nslab; ++y) s += part[(long)y * ncol + c];
+    out[c] = accumulate ? out[c] + s : s;
 }
 
 inline size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -289,36 +651,146 @@ int launch_ok(const char* what) {
     return TG_OK;
 }
 
+
+// ---- fragment operands: 32-row blocks padded to whole 256-row tiles, 16-wide k blocks in pairs
+inline int fg_rb(long R) { return (int)((R + 255) / 256 * 8); }
+inline int fg_kb(long K) { return (int)(2 * ((K + 31) / 32)); }
+inline size_t fg_bytes(long R, long K, int extra_rb = 0) { return (size_t)(fg_rb(R) + extra_rb) * fg_kb(K) * 2 * 64 * 16; }
+
+void to_frag(hipStream_t s, const float* X, long rs, long cs, long R, long K, const float* scal, int si, int RBp, int KB,
+             void* dst) {
+    const long total = (long)RBp * KB * 64;
+    const long want = (total + 255) / 256;
+    hipLaunchKernelGGL(k_to_frag, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0, s, X, rs, cs, (int)R, (int)K,
+                       scal, si, RBp, KB, reinterpret_cast<f16x8*>(dst));
+}
+
+template <int WM, int WN, int TM, int TN>
+int launch_fgemm_t(FgArgs& a, int MBp, hipStream_t s) {
+    constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
+    constexpr size_t sm = (size_t)2 * (WM * TM + WN * TN) * 256 * 16;
+    static TgLdsAttr attr;
+    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_fgemm<WM, WN, TM, TN>), sm, "k_fgemm")) return rc;
+    a.MT = MBp * 32 / BM;
+    a.RT = (a.N + BN - 1) / BN;
+    a.NB = (a.RT + 7) / 8 * 8 * a.MT;
+    const int resident = 256 * (int)((160 * 1024) / sm);
+    int gx = resident / a.nz / 8 * 8;
+    if (gx < 8) gx = 8;
+    if (gx > a.NB) gx = a.NB;
+    a.gx = gx;
+    hipLaunchKernelGGL((k_fgemm<WM, WN, TM, TN>), dim3(gx * a.nz), dim3(64 * WM * WN), sm, s, a);
+    return TG_OK;
+}
+
+// out[n*ldo + m] (+)= scal[inv_idx] * sum_k A(m,k) B(n,k) (+ bias[m]).  MBp = A's 32-row blocks (a multiple of 8).
+// zbuf (>= 8*N*M floats, ldo == M): small problems with a long contraction are cut over k into slices summed in order.
+int fgemm(hipStream_t s, const void* Af, int MBp, const void* Bf, int KB, float* out, long ldo, int M, int N,
+          const float* scal, int inv_idx, const float* bias, bool accumulate, float* zbuf = nullptr) {
+    if (M <= 0 || N <= 0) return TG_OK;
+    FgArgs a = {};
+    a.Af = reinterpret_cast<const f32x4*>(Af);
+    a.Bf = reinterpret_cast<const f32x4*>(Bf);
+    a.KB = KB;
+    a.out = out; a.ldo = ldo; a.zstride = 0; a.nz = 1;
+    a.M = M; a.N = N;
+    a.scal = scal; a.inv_idx = inv_idx; a.bias = bias; a.accumulate = accumulate ? 1 : 0;
+    a.vec = (ldo % 4 == 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+            (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
+    const long big = (long)(MBp / 8) * ((N + 255) / 256), small = (long)(MBp / 4) * ((N + 127) / 128);
+    const double cost_big = (double)((big + 255) / 256) * 4.0 * 0.93, cost_small = (double)((small + 511) / 512) * 2.0;
+    bool use_big = cost_big <= cost_small;
+    const int S = KB / 2;
+    if (zbuf && ldo == M && !accumulate && small < 256 && S >= 64) {
+        int nz = (int)(512 / small);
+        if (nz > 8) nz = 8;
+        if (nz > S / 32) nz = S / 32;
+        if (nz > 1) {
+            use_big = false;
+            a.nz = nz;
+            a.out = zbuf;
+            a.zstride = (long)N * M;
+            a.vec = (M % 4 == 0) && (reinterpret_cast<uintptr_t>(zbuf) & 15) == 0;
+        }
+    }
+    int rc = use_big ? launch_fgemm_t<2, 4, 4, 2>(a, MBp, s) : launch_fgemm_t<2, 2, 2, 2>(a, MBp, s);
+    if (rc) return rc;
+    if (a.nz > 1) {
+        const long n = (long)N * M;
+        hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s,
+                           zbuf, a.nz, a.zstride, n, out);
+    }
+    return TG_OK;
+}
+
+// deterministic column sums of X [rows, ncol] (ld): slabs of kSlab rows, then the slabs in order.  part: >= nslab*ncol
+void colsum(hipStream_t s, const float* X, long ld, long rows, int ncol, float* part, float* out, bool accumulate) {
+    const int nslab = (int)((rows + kSlab - 1) / kSlab);
+    hipLaunchKernelGGL(k_colsum_slab, dim3(blocks(ncol), nslab), dim3(256), 0, s, X, ld, rows, ncol, part);
+    hipLaunchKernelGGL(k_colsum_final, dim3(blocks(ncol)), dim3(256), 0, s, part, nslab, ncol, out, accumulate ? 1 : 0);
+}
+
+// split-fp16 projection: scratch shared by forward and backward
+struct SplitLayout { size_t hdr, Wa1, Hb, total; };
+SplitLayout split_fwd_layout(const TgGenWeights* w, long NL) {
+    SplitLayout o = {};
+    size_t off = 0;
+    o.hdr = off; off += al(256);
+    o.Wa1 = off; off += al(fg_bytes(w->V, w->H));
+    o.Hb = off; off += al(fg_bytes(NL, w->H, 8));
+    o.total = off;
+    return o;
+}
+int split_prepare(const TgGenWeights* w, const float* hs, long NL, const float* coeff, char* base, const SplitLayout& lo,
+                  hipStream_t s) {
+    unsigned* absmax = reinterpret_cast<unsigned*>(base + lo.hdr);
+    float* scal = reinterpret_cast<float*>(base + lo.hdr + 64);
+    if (hipMemsetAsync(absmax, 0, 64, s) != hipSuccess) {
+        tg_set_error("hipMemsetAsync failed");
+        return TG_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(k_absmax_u, dim3(1024), dim3(256), 0, s, w->w_out, (size_t)w->V * w->H, absmax);
+    if (coeff) hipLaunchKernelGGL(k_absmax_u, dim3(64), dim3(256), 0, s, coeff, (size_t)NL, absmax + 1);
+    hipLaunchKernelGGL(k_pgw_scales, dim3(1), dim3(64), 0, s, absmax, scal);
+    to_frag(s, w->w_out, w->H, 1, w->V, w->H, scal, 0, fg_rb(w->V), fg_kb(w->H), base + lo.Wa1);     // A(m = v, k = h)
+    to_frag(s, hs, 2 * w->H, 1, NL, w->H, scal, 1, fg_rb(NL) + 8, fg_kb(w->H), base + lo.Hb);           // B(n = row, k = h)
+    return TG_OK;
+}
+
 }  // namespace
 
 bool tg_pgw_shape_ok(const TgGenWeights* w) {
     return w && w->V >= 1 && w->E >= 32 && w->H >= 32 && w->E <= 1024 && w->H <= 1024 && w->E % 32 == 0 && w->H % 32 == 0;
 }
 
-size_t tg_pgw_forward_workspace_bytes(const TgGenWeights* w, int N, int L, bool have_logits, bool have_states) {
+size_t tg_pgw_forward_workspace_bytes(const TgGenWeights* w, int N, int L, bool have_logits, bool have_states, bool split) {
     const long NL = (long)N * L;
-    size_t b = al(sizeof(int64_t) * NL) + al(sizeof(float) * (size_t)N * 4 * w->H);
+    size_t b = al(sizeof(int64_t) * NL) + al(sizeof(float) * (size_t)NL * 4 * w->H);   // token ids, X W_ih^T of every position
     if (!have_logits) b += al(sizeof(float) * (size_t)chunk_rows(NL, w->V) * w->V);
     if (!have_states) b += al(sizeof(float) * (size_t)(L + 1) * N * 2 * w->H);
+    if (split && !have_logits) b += split_fwd_layout(w, NL).total;
     return b;
 }
 
 int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, int N, int L, float* logp_out,
                    float* lse_out, float* logits_out, float* states_out, void* workspace, size_t workspace_bytes,
-                   hipStream_t s, const float* states_in) {
+                   hipStream_t s, const float* states_in, bool split) {
     const int V = w->V, E = w->E, H = w->H;
     const long NL = (long)N * L;
-    const size_t need = tg_pgw_forward_workspace_bytes(w, N, L, logits_out != nullptr, states_out != nullptr);
+    split = split && !logits_out;   // full logits (parity surface) are always exact fp32
+    const size_t need = tg_pgw_forward_workspace_bytes(w, N, L, logits_out != nullptr, states_out != nullptr, split);
     if (!workspace || workspace_bytes < need) {
         tg_set_error("generator forward (GEMM path): workspace too small (%zu < %zu)", workspace_bytes, need);
         return TG_ERR_WORKSPACE;
     }
     char* ws = (char*)workspace;
     int64_t* idx = (int64_t*)ws; ws += al(sizeof(int64_t) * NL);
-    float* pre = (float*)ws; ws += al(sizeof(float) * (size_t)N * 4 * H);
+    float* preX = (float*)ws; ws += al(sizeof(float) * (size_t)NL * 4 * H);
     float* lchunk = nullptr;
     if (!logits_out) { lchunk = (float*)ws; ws += al(sizeof(float) * (size_t)chunk_rows(NL, V) * V); }
     float* states = states_out ? states_out : (float*)ws;
+    if (!states_out) ws += al(sizeof(float) * (size_t)(L + 1) * N * 2 * H);
+    char* split_base = ws;
     tg_prof_begin(TG_KERNEL_PGW_FORWARD, s);
     hipLaunchKernelGGL(k_tok_tn, dim3(blocks(NL)), dim3(256), 0, s, inp, N, L, idx);
     // slot 0: the initial state -- zeros (init_hidden, generator.py:102-109) or the caller's carried (h,c)
@@ -328,22 +800,40 @@ int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* tar
     else
         hipLaunchKernelGGL(k_zero, dim3(blocks((long)N * 2 * H) < 1024 ? blocks((long)N * 2 * H) : 1024), dim3(256), 0, s,
                            states, (long)N * 2 * H);
-    for (int t = 0; t < L; ++t) {
-        // gates = emb[inp[:, t]] . W_ih^T + h_{t-1} . W_hh^T   (models/generator.py:47-51)
-        gemm<false, false>(s, w->emb, E, w->w_ih, E, pre, 4 * H, N, 4 * H, E, nullptr, false, idx + (long)t * N, nullptr, V);
-        gemm<false, false>(s, states + (long)t * N * 2 * H, 2 * H, w->w_hh, H, pre, 4 * H, N, 4 * H, H, nullptr, true);
-        hipLaunchKernelGGL(k_cell_fwd, dim3(blocks((long)N * H)), dim3(256), 0, s, pre, w->b_ih, w->b_hh, states, N, H, t);
-    }
+    // gates = emb[inp[:, t]] . W_ih^T + h_{t-1} . W_hh^T (models/generator.py:47-51): the input side of every position
+    // as one GEMM, then one launch per position for the recurrent side and the cell
+    gemm<false, false>(s, w->emb, E, w->w_ih, E, preX, 4 * H, (int)NL, 4 * H, E, nullptr, false, idx, nullptr, V);
+    for (int t = 0; t < L; ++t)
+        hipLaunchKernelGGL(k_lstm_step_fwd, dim3(H / 32, (N + 31) / 32), dim3(kStepThreads), 0, s, preX, w->w_hh, w->b_ih,
+                           w->b_hh, states, N, H, t);
     const bool need_proj = (target && logp_out) || lse_out || logits_out;
     if (need_proj) {
         const long rc = chunk_rows(NL, V);
         const float* hs = states + (long)N * 2 * H;   // row r = t*N + n: h after position t
+        const SplitLayout slo = split_fwd_layout(w, NL);
+        if (split) {
+            if (int rc2 = split_prepare(w, hs, NL, nullptr, split_base, slo, s)) return rc2;
+        }
+        const float* scal = reinterpret_cast<const float*>(split_base + slo.hdr + 64);
         for (long r0 = 0; r0 < NL; r0 += rc) {
             const int rows = (int)((NL - r0 < rc) ? NL - r0 : rc);
             // logits_out is [N, L, V] (row n*L + t); the chunk rows are (t, n): with logits_out the chunk is one
             // position t at a time so that the rows of a launch are a strided slice of the output
             if (logits_out) break;
-            gemm<false, false>(s, hs + r0 * 2 * H, 2 * H, w->w_out, H, lchunk, V, rows, V, H, w->b_out);
+            if (split) {
+                tg_prof_end(s);
+                tg_prof_begin(TG_KERNEL_PGW_PROJ, s);
+                if (int rc2 = fgemm(s, split_base + slo.Wa1, fg_rb(V), split_base + slo.Hb + (size_t)(r0 / 32) * fg_kb(H) * 2048,
+                                    fg_kb(H), lchunk, V, V, rows, scal, 2, w->b_out, false)) return rc2;
+                tg_prof_end(s);
+                tg_prof_begin(TG_KERNEL_PGW_FORWARD, s);
+            } else {
+                tg_prof_end(s);
+                tg_prof_begin(TG_KERNEL_PGW_PROJ, s);
+                gemm<false, false>(s, hs + r0 * 2 * H, 2 * H, w->w_out, H, lchunk, V, rows, V, H, w->b_out);
+                tg_prof_end(s);
+                tg_prof_begin(TG_KERNEL_PGW_FORWARD, s);
+            }
             hipLaunchKernelGGL(k_row_softmax, dim3(rows), dim3(256), 0, s, lchunk, (long)V, V, r0, N, L, target, lse_out,
                                logp_out, nullptr, nullptr);
         }
@@ -360,60 +850,123 @@ int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* tar
     return launch_ok("generator forward (GEMM path)");
 }
 
-size_t tg_pgw_backward_workspace_bytes(const TgGenWeights* w, int N, int L) {
+namespace {
+struct BwdLayout { size_t idx, DL, dhproj, DA, P, whhT, dcn, dX, part, split, Wa3, Ha4, DLb3, DLb4, zbuf, total; };
+BwdLayout bwd_layout(const TgGenWeights* w, int N, int L, bool split) {
     const long NL = (long)N * L;
-    const int H = w->H, E = w->E;
-    return al(sizeof(int64_t) * NL) + al(sizeof(float) * (size_t)chunk_rows(NL, w->V) * w->V) +
-           al(sizeof(float) * (size_t)NL * H) + al(sizeof(float) * (size_t)NL * 4 * H) +
-           al(sizeof(float) * (size_t)N * 4 * H) + 2 * al(sizeof(float) * (size_t)N * H) +
-           al(sizeof(float) * (size_t)NL * E);
+    const int H = w->H, E = w->E, V = w->V;
+    const long rc = chunk_rows(NL, V);
+    BwdLayout o = {};
+    size_t off = 0;
+    auto take = [&](size_t bytes) { const size_t at = off; off += al(bytes); return at; };
+    o.idx = take(sizeof(int64_t) * NL);
+    o.DL = take(sizeof(float) * (size_t)rc * V);
+    o.dhproj = take(sizeof(float) * (size_t)NL * H);
+    o.DA = take(sizeof(float) * (size_t)NL * 4 * H);
+    o.P = take(sizeof(float) * (size_t)NL * 4 * H);      // pre-activations of every position (no bias)
+    o.whhT = take(sizeof(float) * (size_t)4 * H * H);    // W_hh^T
+    o.dcn = take(sizeof(float) * (size_t)N * H);
+    o.dX = take(sizeof(float) * (size_t)NL * E);
+    const size_t slabs_dl = (size_t)((rc + kSlab - 1) / kSlab) * V, slabs_da = (size_t)((NL + kSlab - 1) / kSlab) * 4 * H;
+    o.part = take(sizeof(float) * (slabs_dl > slabs_da ? slabs_dl : slabs_da));
+    if (split) {
+        o.split = take(split_fwd_layout(w, NL).total);
+        o.Wa3 = take(fg_bytes(H, V));      // A(m = h, k = v) = W_out^T
+        o.Ha4 = take(fg_bytes(H, rc));     // A(m = h, k = row) = h^T of a chunk
+        o.DLb3 = take(fg_bytes(rc, V));    // B(n = row, k = v) = dlogits
+        o.DLb4 = take(fg_bytes(V, rc));    // B(n = v, k = row) = dlogits^T
+        o.zbuf = take(sizeof(float) * (size_t)8 * rc * H);
+    }
+    o.total = off;
+    return o;
+}
+}  // namespace
+
+size_t tg_pgw_backward_workspace_bytes(const TgGenWeights* w, int N, int L, bool split) {
+    return bwd_layout(w, N, L, split).total;
 }
 
 int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* target, const float* coeff,
                     const float* lse, const float* states, int N, int L, int64_t padding_idx, const TgGenGrads* g,
-                    void* workspace, size_t workspace_bytes, hipStream_t s) {
+                    void* workspace, size_t workspace_bytes, hipStream_t s, bool split) {
     const int V = w->V, E = w->E, H = w->H;
     const long NL = (long)N * L;
-    const size_t need = tg_pgw_backward_workspace_bytes(w, N, L);
-    if (!workspace || workspace_bytes < need) {
-        tg_set_error("tg_gen_pg_backward (GEMM path): workspace of %zu bytes needed, %zu given", need, workspace_bytes);
+    const BwdLayout lo = bwd_layout(w, N, L, split);
+    if (!workspace || workspace_bytes < lo.total) {
+        tg_set_error("tg_gen_pg_backward (GEMM path): workspace of %zu bytes needed, %zu given", lo.total, workspace_bytes);
         return TG_ERR_WORKSPACE;
     }
     char* ws = (char*)workspace;
     const long rc = chunk_rows(NL, V);
-    int64_t* idx = (int64_t*)ws; ws += al(sizeof(int64_t) * NL);
-    float* DL = (float*)ws; ws += al(sizeof(float) * (size_t)rc * V);
-    float* dhproj = (float*)ws; ws += al(sizeof(float) * (size_t)NL * H);
-    float* DA = (float*)ws; ws += al(sizeof(float) * (size_t)NL * 4 * H);
-    float* pre = (float*)ws; ws += al(sizeof(float) * (size_t)N * 4 * H);
-    float* dhn = (float*)ws; ws += al(sizeof(float) * (size_t)N * H);
-    float* dcn = (float*)ws; ws += al(sizeof(float) * (size_t)N * H);
-    float* dX = (float*)ws;
+    int64_t* idx = (int64_t*)(ws + lo.idx);
+    float* DL = (float*)(ws + lo.DL);
+    float* dhproj = (float*)(ws + lo.dhproj);
+    float* DA = (float*)(ws + lo.DA);
+    float* P = (float*)(ws + lo.P);
+    float* whhT = (float*)(ws + lo.whhT);
+    float* dcn = (float*)(ws + lo.dcn);
+    float* dX = (float*)(ws + lo.dX);
+    float* part = (float*)(ws + lo.part);
     tg_prof_begin(TG_KERNEL_PGW_BACKWARD, s);
     hipLaunchKernelGGL(k_tok_tn, dim3(blocks(NL)), dim3(256), 0, s, inp, N, L, idx);
     const float* hs = states + (long)N * 2 * H;   // row r = t*N + n: h after position t (ld 2H)
+    const SplitLayout slo = split_fwd_layout(w, NL);
+    char* sbase = ws + lo.split;
+    const float* scal = reinterpret_cast<const float*>(sbase + slo.hdr + 64);
+    if (split) {
+        if (int rc2 = split_prepare(w, hs, NL, coeff, sbase, slo, s)) return rc2;
+        to_frag(s, w->w_out, 1, H, H, V, scal, 0, fg_rb(H), fg_kb(V), ws + lo.Wa3);
+    }
+    // the three vocabulary products run under their own profile id: close / reopen the bracket around them
+    auto proj_begin = [&](int id = TG_KERNEL_PGW_PROJ) { tg_prof_end(s); tg_prof_begin(id, s); };
+    auto proj_end = [&]() { tg_prof_end(s); tg_prof_begin(TG_KERNEL_PGW_BACKWARD, s); };
     // ---- projection: dh_proj, dW_out, db_out, one chunk of rows at a time
     for (long r0 = 0; r0 < NL; r0 += rc) {
         const int rows = (int)((NL - r0 < rc) ? NL - r0 : rc);
-        gemm<false, false>(s, hs + r0 * 2 * H, 2 * H, w->w_out, H, DL, V, rows, V, H, w->b_out);
+        if (split) {
+            proj_begin();
+            if (int rc2 = fgemm(s, sbase + slo.Wa1, fg_rb(V), sbase + slo.Hb + (size_t)(r0 / 32) * fg_kb(H) * 2048, fg_kb(H),
+                                DL, V, V, rows, scal, 2, w->b_out, false)) return rc2;
+            proj_end();
+        } else {
+            proj_begin();
+            gemm<false, false>(s, hs + r0 * 2 * H, 2 * H, w->w_out, H, DL, V, rows, V, H, w->b_out);
+            proj_end();
+        }
         hipLaunchKernelGGL(k_row_softmax, dim3(rows), dim3(256), 0, s, DL, (long)V, V, r0, N, L, target, nullptr, nullptr,
                            lse, coeff);
-        gemm<false, true>(s, DL, V, w->w_out, H, dhproj + r0 * H, H, rows, H, V);                 // dlogits . W_out
-        gemm<true, true>(s, DL, V, hs + r0 * 2 * H, 2 * H, g->w_out, H, V, H, rows, nullptr, r0 > 0);  // dlogits^T . h
-        hipLaunchKernelGGL(k_colsum, dim3(blocks(V)), dim3(256), 0, s, DL, (long)V, (long)rows, V, g->b_out, r0 > 0 ? 1 : 0);
+        if (split) {
+            to_frag(s, DL, V, 1, rows, V, scal, 3, fg_rb(rc), fg_kb(V), ws + lo.DLb3);
+            to_frag(s, DL, 1, V, V, rows, scal, 3, fg_rb(V), fg_kb(rows), ws + lo.DLb4);
+            to_frag(s, hs + r0 * 2 * H, 1, 2 * H, H, rows, scal, 1, fg_rb(H), fg_kb(rows), ws + lo.Ha4);
+            proj_begin(TG_KERNEL_PGW_PROJ_DH);
+            if (int rc2 = fgemm(s, ws + lo.Wa3, fg_rb(H), ws + lo.DLb3, fg_kb(V), dhproj + r0 * H, H, H, rows, scal, 4, nullptr,
+                                false, (float*)(ws + lo.zbuf))) return rc2;                                   // dlogits . W_out
+            proj_begin(TG_KERNEL_PGW_PROJ_DW);
+            if (int rc2 = fgemm(s, ws + lo.Ha4, fg_rb(H), ws + lo.DLb4, fg_kb(rows), g->w_out, H, H, V, scal, 5, nullptr,
+                                r0 > 0)) return rc2;                                                           // dlogits^T . h
+            proj_end();
+        } else {
+            proj_begin(TG_KERNEL_PGW_PROJ_DH);
+            gemm<false, true>(s, DL, V, w->w_out, H, dhproj + r0 * H, H, rows, H, V);                 // dlogits . W_out
+            proj_begin(TG_KERNEL_PGW_PROJ_DW);
+            gemm<true, true>(s, DL, V, hs + r0 * 2 * H, 2 * H, g->w_out, H, V, H, rows, nullptr, r0 > 0);  // dlogits^T . h
+            proj_end();
+        }
+        colsum(s, DL, (long)V, (long)rows, V, part, g->b_out, r0 > 0);
     }
-    // ---- back through time
-    for (int t = L - 1; t >= 0; --t) {
-        gemm<false, false>(s, w->emb, E, w->w_ih, E, pre, 4 * H, N, 4 * H, E, nullptr, false, idx + (long)t * N, nullptr, V);
-        gemm<false, false>(s, states + (long)t * N * 2 * H, 2 * H, w->w_hh, H, pre, 4 * H, N, 4 * H, H, nullptr, true);
-        hipLaunchKernelGGL(k_bptt_elem, dim3(blocks((long)N * H)), dim3(256), 0, s, pre, w->b_ih, w->b_hh, states, dhproj,
-                           dhn, dcn, DA, N, H, t, t == L - 1 ? 1 : 0);
-        if (t > 0) gemm<false, true>(s, DA + (long)t * N * 4 * H, 4 * H, w->w_hh, H, dhn, H, N, H, 4 * H);  // da . W_hh
-    }
+    // ---- back through time: the pre-activations of every position from two batched GEMMs (all h_{t-1} are saved
+    // states), then one launch per position: dh = dh_proj + da_{t+1} W_hh and the cell's gate gradients
+    gemm<false, false>(s, w->emb, E, w->w_ih, E, P, 4 * H, (int)NL, 4 * H, E, nullptr, false, idx, nullptr, V);
+    gemm<false, false>(s, states, 2 * H, w->w_hh, H, P, 4 * H, (int)NL, 4 * H, H, nullptr, true);
+    hipLaunchKernelGGL(k_transpose, dim3(H / 32, 4 * H / 32), dim3(256), 0, s, w->w_hh, 4 * H, H, whhT);
+    for (int t = L - 1; t >= 0; --t)
+        hipLaunchKernelGGL(k_lstm_step_bwd, dim3(H / 32, (N + 31) / 32), dim3(kStepThreads), 0, s, P, whhT, w->b_ih, w->b_hh,
+                           states, dhproj, dcn, DA, N, H, t, t == L - 1 ? 1 : 0);
     // ---- weight gradients from all steps at once
     gemm<true, true>(s, DA, 4 * H, w->emb, E, g->w_ih, E, 4 * H, E, (int)NL, nullptr, false, nullptr, idx, V);   // DA^T . X
     gemm<true, true>(s, DA, 4 * H, states, 2 * H, g->w_hh, H, 4 * H, H, (int)NL);                                // DA^T . H_prev
-    hipLaunchKernelGGL(k_colsum, dim3(blocks(4 * H)), dim3(256), 0, s, DA, (long)4 * H, NL, 4 * H, g->b_ih, 0);
+    colsum(s, DA, (long)4 * H, NL, 4 * H, part, g->b_ih, false);
     hipLaunchKernelGGL(k_copy, dim3(blocks(4 * H)), dim3(256), 0, s, g->b_ih, g->b_hh, (long)4 * H);
     gemm<false, true>(s, DA, 4 * H, w->w_ih, E, dX, E, (int)NL, E, 4 * H);                                       // DA . W_ih
     hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, g->emb, (long)V * E);

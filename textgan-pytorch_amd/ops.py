@@ -96,10 +96,11 @@ def gen_nll(gen, inp, target, precision=None, want_lse=False):
 
 
 @_on_device
-def gen_pg_forward(gen, inp, target):
+def gen_pg_forward(gen, inp, target, precision=None):
     """tg_gen_pg_forward: logp / lse / states of a teacher-forced pass, row-parallel projection (few sequences).
-    Same dict as gen_teacher_forced(want_lse=True, want_states=True)."""
-    w, keep = _lib.gen_weights(gen, teacher=True)
+    Same dict as gen_teacher_forced(want_lse=True, want_states=True).  precision (beyond E = H = 32): arithmetic of the
+    vocabulary product, "split_f16" (default) or "fp32"."""
+    w, keep = _lib.gen_weights(gen, precision, teacher=True)
     inp, _ = _tokens(inp, "inp")
     target, _ = _tokens(target, "target")
     N, L = inp.shape
@@ -116,11 +117,12 @@ def gen_pg_forward(gen, inp, target):
 
 
 @_on_device
-def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1):
+def gen_pg_backward(gen, inp, target, coeff, lse, states, padding_idx=-1, precision=None):
     """tg_gen_pg_backward: gradients of sum(coeff-weighted log-probabilities of the targets) with respect to the
     seven generator parameters (what autograd produces behind SeqGAN_G.batchPGLoss, models/SeqGAN_G.py:21-39).
-    Returns a tuple in GenW order: (emb, w_ih, w_hh, b_ih, b_hh, w_out, b_out)."""
-    w, keep = _lib.gen_weights(gen, teacher=True)
+    Returns a tuple in GenW order: (emb, w_ih, w_hh, b_ih, b_hh, w_out, b_out).  precision: as gen_pg_forward (the two
+    halves of one step must use the same one: the backward recomputes the logits the forward's lse belongs to)."""
+    w, keep = _lib.gen_weights(gen, precision, teacher=True)
     inp, _ = _tokens(inp, "inp")
     target, _ = _tokens(target, "target")
     N, L = inp.shape
