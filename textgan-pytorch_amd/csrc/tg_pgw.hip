@@ -28,6 +28,8 @@ struct GemmP {
     const int64_t* a_gather; const int64_t* b_gather;
     long lda, ldb, ldc;
     int M, N, K, accumulate, gather_max;
+    int kslice;       // k range of one blockIdx.z (a multiple of kBK; K when the contraction is not cut)
+    long zstride;     // C offset per blockIdx.z (slices are summed afterwards in fixed order: k_sum_slices)
 };
 
 template <bool KMAJOR>
@@ -85,18 +87,19 @@ __global__ __launch_bounds__(256) void k_gemm32(const GemmP p) {
     const int i = lane & 31, kk = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * kBM, n0 = blockIdx.x * kBN;
+    const int kbeg = (int)blockIdx.z * p.kslice, kend = kbeg + p.kslice < p.K ? kbeg + p.kslice : p.K;
     f32x16 acc[2][2] = {};
     f32x4 va[4], vb[4];
-    g_fetch<A_KMAJOR>(va, p.A, p.lda, p.a_gather, p.gather_max, m0, p.M, 0, p.K, tid);
-    g_fetch<B_KMAJOR>(vb, p.B, p.ldb, p.b_gather, p.gather_max, n0, p.N, 0, p.K, tid);
-    for (int k0 = 0; k0 < p.K; k0 += kBK) {
+    g_fetch<A_KMAJOR>(va, p.A, p.lda, p.a_gather, p.gather_max, m0, p.M, kbeg, kend, tid);
+    g_fetch<B_KMAJOR>(vb, p.B, p.ldb, p.b_gather, p.gather_max, n0, p.N, kbeg, kend, tid);
+    for (int k0 = kbeg; k0 < kend; k0 += kBK) {
         __syncthreads();
         g_commit<A_KMAJOR>(va, As, tid);
         g_commit<B_KMAJOR>(vb, Bs, tid);
         __syncthreads();
-        if (k0 + kBK < p.K) {
-            g_fetch<A_KMAJOR>(va, p.A, p.lda, p.a_gather, p.gather_max, m0, p.M, k0 + kBK, p.K, tid);
-            g_fetch<B_KMAJOR>(vb, p.B, p.ldb, p.b_gather, p.gather_max, n0, p.N, k0 + kBK, p.K, tid);
+        if (k0 + kBK < kend) {
+            g_fetch<A_KMAJOR>(va, p.A, p.lda, p.a_gather, p.gather_max, m0, p.M, k0 + kBK, kend, tid);
+            g_fetch<B_KMAJOR>(vb, p.B, p.ldb, p.b_gather, p.gather_max, n0, p.N, k0 + kBK, kend, tid);
         }
 #pragma unroll
         for (int kp = 0; kp < kBK / 2; ++kp) {
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(256) void k_gemm32(const GemmP p) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * 64 + qa * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 if (m >= p.M) continue;
-                float* c = p.C + (long)m * p.ldc + n;
+                float* c = p.C + (long)blockIdx.z * p.zstride + (long)m * p.ldc + n;
                 const float v = acc[qa][qb][r] + bv;
                 *c = p.accumulate ? *c + v : v;
             }
@@ -133,7 +136,7 @@ void gemm(hipStream_t s, const float* A, long lda, const float* B, long ldb, flo
           const float* bias = nullptr, bool accumulate = false, const int64_t* a_gather = nullptr,
           const int64_t* b_gather = nullptr, int gather_max = 0) {
     if (M <= 0 || N <= 0) return;
-    GemmP p = {A, B, C, bias, a_gather, b_gather, lda, ldb, ldc, M, N, K, accumulate ? 1 : 0, gather_max};
+    GemmP p = {A, B, C, bias, a_gather, b_gather, lda, ldb, ldc, M, N, K, accumulate ? 1 : 0, gather_max, K, 0};
     hipLaunchKernelGGL((k_gemm32<AK, BK>), dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM), dim3(256), 0, s, p);
 }
 
@@ -161,56 +164,77 @@ __global__ __launch_bounds__(256) void k_zero(float* p, long n) {
 // being free as long as A and B agree), partial tiles summed through LDS in wave order, then the element-wise part
 // with threads remapped so that consecutive threads own consecutive units (coalesced state / gradient rows).
 constexpr int kStepThreads = 512;
-constexpr int kPartLd = 33;
+#define TG_MFMA16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-// acc += A[row_a][k] . B[row_b][k] over chunks [c0, c1) of 32 k: lane (i = lane & 31, hh = lane >> 5) feeds k = 32 c +
-// 16 hh + q, q = 0..15, to the q-th MFMA on both operands
-__device__ __forceinline__ void step_dot(f32x16& acc, const float* __restrict__ arow, const float* __restrict__ brow, int hh,
-                                         int c0, int c1) {
+// The tile of one workgroup is T units x T rows, T = 32 (v_mfma_f32_32x32x2_f32) or, when 32 x 32 tiles would leave
+// most of the chip idle (an adversarial batch: 64 rows), T = 16 (v_mfma_f32_16x16x4_f32: four times the workgroups, a
+// quarter of the MFMA cycles each).  Lane (i = lane % T, kg = lane / T) holds T / 2 consecutive k of row i per chunk
+// of 32 k and feeds the q-th of them to the q-th MFMA on both operands (the MFMA's k order is free as long as A and B agree).
+template <int T> struct StepAcc { typedef f32x16 type; };
+template <> struct StepAcc<16> { typedef f32x4v type; };
+
+template <int T>
+__device__ __forceinline__ void step_dot(typename StepAcc<T>::type& acc, const float* __restrict__ arow,
+                                         const float* __restrict__ brow, int kg, int c0, int c1) {
+    constexpr int KP = T / 2;            // k per lane and chunk of 32: 16 (T = 32, two k groups) or 8 (T = 16, four)
+    constexpr int NQ = KP / 4;           // 16-byte loads per operand and chunk
     for (int c = c0; c < c1; c += 4) {
-        f32x4 av[4][4], bv[4][4];
+        f32x4 av[4][NQ], bv[4][NQ];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int cc = c + j < c1 ? c + j : c1 - 1;
-            const f32x4* pa = reinterpret_cast<const f32x4*>(arow + 32 * cc + 16 * hh);
-            const f32x4* pb = reinterpret_cast<const f32x4*>(brow + 32 * cc + 16 * hh);
+            const f32x4* pa = reinterpret_cast<const f32x4*>(arow + 32 * cc + KP * kg);
+            const f32x4* pb = reinterpret_cast<const f32x4*>(brow + 32 * cc + KP * kg);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) { av[j][q] = pa[q]; bv[j][q] = pb[q]; }
+            for (int q = 0; q < NQ; ++q) { av[j][q] = pa[q]; bv[j][q] = pb[q]; }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (c + j < c1) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < NQ; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = TG_MFMA32(av[j][q][e], bv[j][q][e], acc);
+                    for (int e = 0; e < 4; ++e) {
+                        if constexpr (T == 32) acc = TG_MFMA32(av[j][q][e], bv[j][q][e], acc);
+                        else acc = TG_MFMA16x4(av[j][q][e], bv[j][q][e], acc);
+                    }
             }
         }
     }
 }
 
+// this lane's accumulator -> part[unit][row] of its wave (D layouts of the two MFMAs)
+template <int T>
+__device__ __forceinline__ void step_spill(const typename StepAcc<T>::type& acc, float (*part)[T + 1], int i, int kg) {
+    if constexpr (T == 32) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) part[(r & 3) + 8 * (r >> 2) + 4 * kg][i] = acc[r];
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) part[4 * kg + r][i] = acc[r];
+    }
+}
+
 // Forward position t: gates = preX[t] + b_ih + b_hh + h_{t-1} W_hh^T, cell -> states[t+1]   (models/generator.py:51)
 // wave w: gate w & 3, k half w >> 2.  preX [L*N, 4H] (row t*N + n), states [L+1, N, 2, H].
+template <int T>
 __global__ __launch_bounds__(kStepThreads) void k_lstm_step_fwd(const float* __restrict__ preX, const float* __restrict__ w_hh,
                                                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                                 float* __restrict__ states, int N, int H, int t) {
-    __shared__ float part[8][32][kPartLd];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, hh = lane >> 5;
-    const int u0 = 32 * blockIdx.x, n0 = 32 * blockIdx.y;
+    __shared__ float part[8][T][T + 1];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane % T, kg = lane / T;
+    const int u0 = T * blockIdx.x, n0 = T * blockIdx.y;
     const int g = w & 3, kh = w >> 2;
     const int nc = H >> 5, half = (nc + 1) >> 1;
     const int nrow = n0 + i < N ? n0 + i : N - 1;
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    step_dot(acc, w_hh + (size_t)(g * H + u0 + i) * H, states + ((size_t)t * N + nrow) * 2 * H, hh,
-             kh ? half : 0, kh ? nc : half);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
+    typename StepAcc<T>::type acc = {};
+    step_dot<T>(acc, w_hh + (size_t)(g * H + u0 + i) * H, states + ((size_t)t * N + nrow) * 2 * H, kg,
+                kh ? half : 0, kh ? nc : half);
+    step_spill<T>(acc, part[w], i, kg);
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int p = tid + kStepThreads * q, u = p & 31, nl = p >> 5, n = n0 + nl;
+    for (int p = tid; p < T * T; p += kStepThreads) {
+        const int u = p % T, nl = p / T, n = n0 + nl;
         if (n >= N) continue;
         const size_t row = (size_t)t * N + n;
         float gate[4];
@@ -230,29 +254,26 @@ __global__ __launch_bounds__(kStepThreads) void k_lstm_step_fwd(const float* __r
 
 // Backward position t: dh = dhproj[t] + da_{t+1} W_hh, then the cell's gate gradients da_t -> DA[t], dc carried in dcn.
 // P [L*N, 4H]: pre-activations without bias (X W_ih^T + H_prev W_hh^T); w_hhT [H, 4H]; wave w: k slice w of 8.
+template <int T>
 __global__ __launch_bounds__(kStepThreads) void k_lstm_step_bwd(const float* __restrict__ P, const float* __restrict__ w_hhT,
                                                                 const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                                 const float* __restrict__ states, const float* __restrict__ dhproj,
                                                                 float* __restrict__ dcn, float* __restrict__ DA, int N, int H,
                                                                 int t, int last) {
-    __shared__ float part[8][32][kPartLd];
-    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane & 31, hh = lane >> 5;
-    const int u0 = 32 * blockIdx.x, n0 = 32 * blockIdx.y;
+    __shared__ float part[8][T][T + 1];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane % T, kg = lane / T;
+    const int u0 = T * blockIdx.x, n0 = T * blockIdx.y;
     if (!last) {
         const int nc = (4 * H) >> 5;                    // a multiple of 4
         const int c0 = (int)((long)nc * w / 8), c1 = (int)((long)nc * (w + 1) / 8);
         const int nrow = n0 + i < N ? n0 + i : N - 1;
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-        step_dot(acc, w_hhT + (size_t)(u0 + i) * 4 * H, DA + ((size_t)(t + 1) * N + nrow) * 4 * H, hh, c0, c1);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) part[w][(r & 3) + 8 * (r >> 2) + 4 * hh][i] = acc[r];
+        typename StepAcc<T>::type acc = {};
+        step_dot<T>(acc, w_hhT + (size_t)(u0 + i) * 4 * H, DA + ((size_t)(t + 1) * N + nrow) * 4 * H, kg, c0, c1);
+        step_spill<T>(acc, part[w], i, kg);
         __syncthreads();
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int p = tid + kStepThreads * q, u = p & 31, nl = p >> 5, n = n0 + nl;
+    for (int p = tid; p < T * T; p += kStepThreads) {
+        const int u = p % T, nl = p / T, n = n0 + nl;
         if (n >= N) continue;
         const size_t row = (size_t)t * N + n;
         const int uu = u0 + u;
@@ -459,9 +480,11 @@ struct FgArgs {
     int M, N, vec, accumulate;
     const float* scal; int inv_idx;
     const float* bias;
+    int tstore;   // 1: out[m*ldo + n] (+ bias[n]) -- the 32 lanes of a store are 32 consecutive n: whole 128-byte lines per
+                  // instruction where the 16-byte form (4 consecutive m per lane, rows ldo apart) writes 32-byte pieces
 };
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, bool TSTORE>
 __global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void k_fgemm(const FgArgs a) {
     constexpr int NTHR = 64 * WM * WN;
@@ -555,7 +578,33 @@ void k_fgemm(const FgArgs a) {
             __syncthreads();
         }
         // ---- epilogue: D reg r of lane (n, hh) -> m = 32 mb + (r&3) + 8 (r>>2) + 4 hh, row 32 rb + n
-        {
+        if constexpr (TSTORE) {
+            const float inv = a.scal[a.inv_idx];
+            const int mbw = mb0 + TM * wm, rbw = rb0 + TN * wn;
+#pragma unroll
+            for (int ni = 0; ni < TN; ++ni) {
+                const int col = 32 * (rbw + ni) + n;
+                const bool col_ok = col < a.N;
+                const float bv = (a.bias && col_ok) ? a.bias[col] : 0.f;
+                // one running pointer, advanced row by row (128 precomputed 64-bit addresses would not fit the registers)
+                float* d = outz + (size_t)(32 * mbw + 4 * hh) * a.ldo + col;
+                int m = 32 * mbw + 4 * hh;
+#pragma unroll
+                for (int mi = 0; mi < TM; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (col_ok && m < a.M) {
+                            float v = acc[mi][ni][r] * inv + bv;
+                            if (a.accumulate) v += *d;
+                            *d = v;
+                        }
+                        const int adv = (r & 3) == 3 ? 5 : 1;   // rows (r&3) + 8 (r>>2): +1 three times, then +5
+                        d += (size_t)adv * a.ldo;
+                        m += adv;
+                        asm volatile("" : "+v"(d), "+v"(m));
+                    }
+            }
+        } else {
             const float inv = a.scal[a.inv_idx];
             const int mbw = mb0 + TM * wm, rbw = rb0 + TN * wn;
 #pragma unroll
@@ -669,8 +718,10 @@ template <int WM, int WN, int TM, int TN>
 int launch_fgemm_t(FgArgs& a, int MBp, hipStream_t s) {
     constexpr int BM = 32 * WM * TM, BN = 32 * WN * TN;
     constexpr size_t sm = (size_t)2 * (WM * TM + WN * TN) * 256 * 16;
-    static TgLdsAttr attr;
-    if (int rc = tg_lds_attr(attr, reinterpret_cast<const void*>(&k_fgemm<WM, WN, TM, TN>), sm, "k_fgemm")) return rc;
+    static TgLdsAttr attr_n, attr_t;
+    if (int rc = a.tstore ? tg_lds_attr(attr_t, reinterpret_cast<const void*>(&k_fgemm<WM, WN, TM, TN, true>), sm, "k_fgemm")
+                          : tg_lds_attr(attr_n, reinterpret_cast<const void*>(&k_fgemm<WM, WN, TM, TN, false>), sm, "k_fgemm"))
+        return rc;
     a.MT = MBp * 32 / BM;
     a.RT = (a.N + BN - 1) / BN;
     a.NB = (a.RT + 7) / 8 * 8 * a.MT;
@@ -679,14 +730,17 @@ int launch_fgemm_t(FgArgs& a, int MBp, hipStream_t s) {
     if (gx < 8) gx = 8;
     if (gx > a.NB) gx = a.NB;
     a.gx = gx;
-    hipLaunchKernelGGL((k_fgemm<WM, WN, TM, TN>), dim3(gx * a.nz), dim3(64 * WM * WN), sm, s, a);
+    if (a.tstore) hipLaunchKernelGGL((k_fgemm<WM, WN, TM, TN, true>), dim3(gx * a.nz), dim3(64 * WM * WN), sm, s, a);
+    else hipLaunchKernelGGL((k_fgemm<WM, WN, TM, TN, false>), dim3(gx * a.nz), dim3(64 * WM * WN), sm, s, a);
     return TG_OK;
 }
 
-// out[n*ldo + m] (+)= scal[inv_idx] * sum_k A(m,k) B(n,k) (+ bias[m]).  MBp = A's 32-row blocks (a multiple of 8).
-// zbuf (>= 8*N*M floats, ldo == M): small problems with a long contraction are cut over k into slices summed in order.
+// out[n*ldo + m] (+)= scal[inv_idx] * sum_k A(m,k) B(n,k) (+ bias[m])  -- or, tstore, out[m*ldo + n] (+ bias[n]).
+// MBp = A's 32-row blocks (a multiple of 8).  zbuf (>= kMaxSlices*N*M floats; dense output, no accumulate): a problem
+// with few tiles and a long contraction is cut over k into slices, one workgroup each, summed afterwards in order.
+constexpr int kMaxSlices = 16;
 int fgemm(hipStream_t s, const void* Af, int MBp, const void* Bf, int KB, float* out, long ldo, int M, int N,
-          const float* scal, int inv_idx, const float* bias, bool accumulate, float* zbuf = nullptr) {
+          const float* scal, int inv_idx, const float* bias, bool accumulate, float* zbuf = nullptr, bool tstore = false) {
     if (M <= 0 || N <= 0) return TG_OK;
     FgArgs a = {};
     a.Af = reinterpret_cast<const f32x4*>(Af);
@@ -695,23 +749,38 @@ int fgemm(hipStream_t s, const void* Af, int MBp, const void* Bf, int KB, float*
     a.out = out; a.ldo = ldo; a.zstride = 0; a.nz = 1;
     a.M = M; a.N = N;
     a.scal = scal; a.inv_idx = inv_idx; a.bias = bias; a.accumulate = accumulate ? 1 : 0;
-    a.vec = (ldo % 4 == 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+    a.tstore = tstore ? 1 : 0;
+    a.vec = !tstore && (ldo % 4 == 0) && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
             (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0);
-    const long big = (long)(MBp / 8) * ((N + 255) / 256), small = (long)(MBp / 4) * ((N + 127) / 128);
-    const double cost_big = (double)((big + 255) / 256) * 4.0 * 0.93, cost_small = (double)((small + 511) / 512) * 2.0;
-    bool use_big = cost_big <= cost_small;
+    // shape and slices: passes over the chip x k steps per workgroup x cost of a step (a 256 x 256 tile moves half the
+    // operand bytes per flop: 4 x 0.93 of a 128 x 128 step on a CU of its own; two small workgroups share a CU: 2)
     const int S = KB / 2;
-    if (zbuf && ldo == M && !accumulate && small < 256 && S >= 64) {
-        int nz = (int)(512 / small);
-        if (nz > 8) nz = 8;
-        if (nz > S / 32) nz = S / 32;
-        if (nz > 1) {
-            use_big = false;
-            a.nz = nz;
-            a.out = zbuf;
-            a.zstride = (long)N * M;
-            a.vec = (M % 4 == 0) && (reinterpret_cast<uintptr_t>(zbuf) & 15) == 0;
+    const bool can_slice = zbuf && !tstore && ldo == M && !accumulate;
+    double best = 1e300;
+    bool use_big = true;
+    int best_nz = 1;
+    for (int shape = 0; shape < 2; ++shape) {
+        // as launch_fgemm_t lays the grid out: NB logical tiles (row tiles rounded up to 8), gx workgroups per slice
+        const int BM = shape == 0 ? 256 : 128;
+        const int MT = MBp * 32 / BM, RT = (N + BM - 1) / BM, NB = (RT + 7) / 8 * 8 * MT;
+        const int slots = shape == 0 ? 256 : 512;
+        const double step = shape == 0 ? 4.0 * 0.93 : 2.0;
+        for (int nz = 1; nz <= (can_slice ? kMaxSlices : 1); ++nz) {
+            if (nz > 1 && S / nz < 16) break;
+            int gx = slots / nz / 8 * 8;
+            if (gx < 8) gx = 8;
+            if (gx > NB) gx = NB;
+            const int passes = (NB / 8 + gx / 8 - 1) / (gx / 8);
+            const double cost = (double)passes * ((S + nz - 1) / nz + 4) * step;
+            if (cost < best * (shape == 1 ? 0.9 : 1.0)) { best = cost; use_big = shape == 0; best_nz = nz; }   // ties go to the big tile
         }
+    }
+    if (best_nz > 1) {
+        a.nz = best_nz;
+        a.out = zbuf;
+        a.ldo = M;
+        a.zstride = (long)N * M;
+        a.vec = (M % 4 == 0) && (reinterpret_cast<uintptr_t>(zbuf) & 15) == 0;
     }
     int rc = use_big ? launch_fgemm_t<2, 4, 4, 2>(a, MBp, s) : launch_fgemm_t<2, 2, 2, 2>(a, MBp, s);
     if (rc) return rc;
@@ -721,6 +790,26 @@ int fgemm(hipStream_t s, const void* Af, int MBp, const void* Bf, int KB, float*
                            zbuf, a.nz, a.zstride, n, out);
     }
     return TG_OK;
+}
+
+// k_gemm32 with the contraction cut over blockIdx.z when the output has too few tiles to fill the chip (the weight
+// gradients: [4H, E] from thousands of token rows): slices into zbuf [nz][M][N], summed in order into C (ldc == N).
+template <bool AK, bool BK>
+void gemm_sliced(hipStream_t s, const float* A, long lda, const float* B, long ldb, float* C, int M, int N, int K,
+                 float* zbuf, const int64_t* a_gather = nullptr, const int64_t* b_gather = nullptr, int gather_max = 0) {
+    if (M <= 0 || N <= 0) return;
+    const long tiles = (long)((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM);
+    int nz = (int)(512 / tiles);
+    if (nz > kMaxSlices) nz = kMaxSlices;
+    if (nz > K / (8 * kBK)) nz = K / (8 * kBK);
+    if (nz < 2) { gemm<AK, BK>(s, A, lda, B, ldb, C, N, M, N, K, nullptr, false, a_gather, b_gather, gather_max); return; }
+    const int kslice = ((K + nz - 1) / nz + kBK - 1) / kBK * kBK;
+    nz = (K + kslice - 1) / kslice;
+    GemmP p = {A, B, zbuf, nullptr, a_gather, b_gather, lda, ldb, (long)N, M, N, K, 0, gather_max, kslice, (long)M * N};
+    hipLaunchKernelGGL((k_gemm32<AK, BK>), dim3((N + kBN - 1) / kBN, (M + kBM - 1) / kBM, nz), dim3(256), 0, s, p);
+    const long n = (long)M * N;
+    hipLaunchKernelGGL(k_sum_slices, dim3((unsigned)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096)), dim3(256), 0, s, zbuf,
+                       nz, (long)M * N, n, C);
 }
 
 // deterministic column sums of X [rows, ncol] (ld): slabs of kSlab rows, then the slabs in order.  part: >= nslab*ncol
@@ -803,9 +892,15 @@ int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* tar
     // gates = emb[inp[:, t]] . W_ih^T + h_{t-1} . W_hh^T (models/generator.py:47-51): the input side of every position
     // as one GEMM, then one launch per position for the recurrent side and the cell
     gemm<false, false>(s, w->emb, E, w->w_ih, E, preX, 4 * H, (int)NL, 4 * H, E, nullptr, false, idx, nullptr, V);
-    for (int t = 0; t < L; ++t)
-        hipLaunchKernelGGL(k_lstm_step_fwd, dim3(H / 32, (N + 31) / 32), dim3(kStepThreads), 0, s, preX, w->w_hh, w->b_ih,
-                           w->b_hh, states, N, H, t);
+    const bool small_tiles = (long)(H / 32) * ((N + 31) / 32) < 256;   // 32 x 32 tiles would not fill the chip
+    for (int t = 0; t < L; ++t) {
+        if (small_tiles)
+            hipLaunchKernelGGL(k_lstm_step_fwd<16>, dim3(H / 16, (N + 15) / 16), dim3(kStepThreads), 0, s, preX, w->w_hh,
+                               w->b_ih, w->b_hh, states, N, H, t);
+        else
+            hipLaunchKernelGGL(k_lstm_step_fwd<32>, dim3(H / 32, (N + 31) / 32), dim3(kStepThreads), 0, s, preX, w->w_hh,
+                               w->b_ih, w->b_hh, states, N, H, t);
+    }
     const bool need_proj = (target && logp_out) || lse_out || logits_out;
     if (need_proj) {
         const long rc = chunk_rows(NL, V);
@@ -823,8 +918,10 @@ int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* tar
             if (split) {
                 tg_prof_end(s);
                 tg_prof_begin(TG_KERNEL_PGW_PROJ, s);
-                if (int rc2 = fgemm(s, split_base + slo.Wa1, fg_rb(V), split_base + slo.Hb + (size_t)(r0 / 32) * fg_kb(H) * 2048,
-                                    fg_kb(H), lchunk, V, V, rows, scal, 2, w->b_out, false)) return rc2;
+                // operands swapped (M = rows, N = vocabulary) with the transposed store: a lane's column is a vocabulary entry
+                if (int rc2 = fgemm(s, split_base + slo.Hb + (size_t)(r0 / 32) * fg_kb(H) * 2048, fg_rb(rows),
+                                    split_base + slo.Wa1, fg_kb(H), lchunk, V, rows, V, scal, 2, w->b_out, false, nullptr,
+                                    true)) return rc2;
                 tg_prof_end(s);
                 tg_prof_begin(TG_KERNEL_PGW_FORWARD, s);
             } else {
@@ -851,7 +948,7 @@ int tg_pgw_forward(const TgGenWeights* w, const int64_t* inp, const int64_t* tar
 }
 
 namespace {
-struct BwdLayout { size_t idx, DL, dhproj, DA, P, whhT, dcn, dX, part, split, Wa3, Ha4, DLb3, DLb4, zbuf, total; };
+struct BwdLayout { size_t idx, DL, dhproj, DA, P, whhT, dcn, dX, part, gz, split, Wa3, Ha4, DLb3, DLb4, zbuf, total; };
 BwdLayout bwd_layout(const TgGenWeights* w, int N, int L, bool split) {
     const long NL = (long)N * L;
     const int H = w->H, E = w->E, V = w->V;
@@ -869,13 +966,14 @@ BwdLayout bwd_layout(const TgGenWeights* w, int N, int L, bool split) {
     o.dX = take(sizeof(float) * (size_t)NL * E);
     const size_t slabs_dl = (size_t)((rc + kSlab - 1) / kSlab) * V, slabs_da = (size_t)((NL + kSlab - 1) / kSlab) * 4 * H;
     o.part = take(sizeof(float) * (slabs_dl > slabs_da ? slabs_dl : slabs_da));
+    o.gz = take(sizeof(float) * (size_t)kMaxSlices * 4 * H * (E > H ? E : H));   // k slices of the weight-gradient GEMMs
     if (split) {
         o.split = take(split_fwd_layout(w, NL).total);
         o.Wa3 = take(fg_bytes(H, V));      // A(m = h, k = v) = W_out^T
         o.Ha4 = take(fg_bytes(H, rc));     // A(m = h, k = row) = h^T of a chunk
         o.DLb3 = take(fg_bytes(rc, V));    // B(n = row, k = v) = dlogits
         o.DLb4 = take(fg_bytes(V, rc));    // B(n = v, k = row) = dlogits^T
-        o.zbuf = take(sizeof(float) * (size_t)8 * rc * H);
+        o.zbuf = take(sizeof(float) * (size_t)kMaxSlices * rc * H);
     }
     o.total = off;
     return o;
@@ -925,8 +1023,8 @@ int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* ta
         const int rows = (int)((NL - r0 < rc) ? NL - r0 : rc);
         if (split) {
             proj_begin();
-            if (int rc2 = fgemm(s, sbase + slo.Wa1, fg_rb(V), sbase + slo.Hb + (size_t)(r0 / 32) * fg_kb(H) * 2048, fg_kb(H),
-                                DL, V, V, rows, scal, 2, w->b_out, false)) return rc2;
+            if (int rc2 = fgemm(s, sbase + slo.Hb + (size_t)(r0 / 32) * fg_kb(H) * 2048, fg_rb(rows), sbase + slo.Wa1, fg_kb(H),
+                                DL, V, rows, V, scal, 2, w->b_out, false, nullptr, true)) return rc2;
             proj_end();
         } else {
             proj_begin();
@@ -960,12 +1058,19 @@ int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* ta
     gemm<false, false>(s, w->emb, E, w->w_ih, E, P, 4 * H, (int)NL, 4 * H, E, nullptr, false, idx, nullptr, V);
     gemm<false, false>(s, states, 2 * H, w->w_hh, H, P, 4 * H, (int)NL, 4 * H, H, nullptr, true);
     hipLaunchKernelGGL(k_transpose, dim3(H / 32, 4 * H / 32), dim3(256), 0, s, w->w_hh, 4 * H, H, whhT);
-    for (int t = L - 1; t >= 0; --t)
-        hipLaunchKernelGGL(k_lstm_step_bwd, dim3(H / 32, (N + 31) / 32), dim3(kStepThreads), 0, s, P, whhT, w->b_ih, w->b_hh,
-                           states, dhproj, dcn, DA, N, H, t, t == L - 1 ? 1 : 0);
+    const bool small_tiles = (long)(H / 32) * ((N + 31) / 32) < 256;
+    for (int t = L - 1; t >= 0; --t) {
+        if (small_tiles)
+            hipLaunchKernelGGL(k_lstm_step_bwd<16>, dim3(H / 16, (N + 15) / 16), dim3(kStepThreads), 0, s, P, whhT, w->b_ih,
+                               w->b_hh, states, dhproj, dcn, DA, N, H, t, t == L - 1 ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_lstm_step_bwd<32>, dim3(H / 32, (N + 31) / 32), dim3(kStepThreads), 0, s, P, whhT, w->b_ih,
+                               w->b_hh, states, dhproj, dcn, DA, N, H, t, t == L - 1 ? 1 : 0);
+    }
     // ---- weight gradients from all steps at once
-    gemm<true, true>(s, DA, 4 * H, w->emb, E, g->w_ih, E, 4 * H, E, (int)NL, nullptr, false, nullptr, idx, V);   // DA^T . X
-    gemm<true, true>(s, DA, 4 * H, states, 2 * H, g->w_hh, H, 4 * H, H, (int)NL);                                // DA^T . H_prev
+    float* gz = (float*)(ws + lo.gz);
+    gemm_sliced<true, true>(s, DA, 4 * H, w->emb, E, g->w_ih, 4 * H, E, (int)NL, gz, nullptr, idx, V);             // DA^T . X
+    gemm_sliced<true, true>(s, DA, 4 * H, states, 2 * H, g->w_hh, 4 * H, H, (int)NL, gz);                         // DA^T . H_prev
     colsum(s, DA, (long)4 * H, NL, 4 * H, part, g->b_ih, false);
     hipLaunchKernelGGL(k_copy, dim3(blocks(4 * H)), dim3(256), 0, s, g->b_ih, g->b_hh, (long)4 * H);
     gemm<false, true>(s, DA, 4 * H, w->w_ih, E, dX, E, (int)NL, E, 4 * H);                                       // DA . W_ih
