@@ -350,7 +350,7 @@ int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
  *                           worker and to the feature extractor)
  *   completions [R,T,B,L]   int64; only i in [i_lo, i_hi) is written
  *   workspace   tg_leak_rollout_workspace_bytes(g, d, B, L, T, i_hi - i_lo) bytes
- * Supported: hidden size a multiple of 32 up to 128, goal_size <= 64, V <= 32768, B <= goal_init's rows; the scorer
+ * Supported: hidden size a multiple of 32 up to 128, goal_size <= 64, V <= 65536, B <= goal_init's rows; the scorer
  * as in tg_dis_score (d->precision selects its arithmetic; the generator side is fp32 MFMA / fp64). */
 typedef struct TgLeakWeights {
     const float* emb;       /* embeddings.weight     [V,E]    */

@@ -428,6 +428,30 @@ def test_discriminator_ragged_and_dropout(N, precision):
     np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
+@pytest.mark.parametrize("Ed", [32, 48, 8])
+def test_discriminator_narrower_embedding(Ed, precision):
+    """CNNDiscriminator takes any embed_dim (models/discriminator.py:20-36; cfg.dis_embed_dim is a command-line flag).
+    Narrower than the kernels' 64: the shim zero-pads embedding and conv-weight columns per call, which is exact;
+    features, logits and rewards against the oracle run on the Ed-wide state_dict itself.  Wider: refused."""
+    V, L, N = 211, 22, 45
+    sd = synth.dis_state(V, Ed, *synth.SEQGAN_D_FILTERS, n_out=2, seed=12)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(Ed, V), sd, DEV)
+    od = oracle.Dis(sd)
+    assert od.Ed == Ed
+    seqs = synth.tokens(N, (N, L), V)
+    du = synth.uniform01(N + 1, (N, od.F))
+    o = oracle.dis_forward(od, seqs, col=1, dropout_p=0.25, dropout_uniforms=du, want_feature=True)
+    r = tg.ops.dis_score(dis, _t(seqs), col=1, dropout_p=0.25, dropout_uniforms=_t(du), want_logits=True,
+                         want_feature=True, precision=precision)
+    np.testing.assert_allclose(r["feature"].cpu().numpy(), o["feature"], rtol=1e-4, atol=2e-6)
+    np.testing.assert_allclose(r["logits"].cpu().numpy(), o["logits"], rtol=1e-4, atol=5e-6)
+    np.testing.assert_allclose(r["reward"].cpu().numpy(), o["reward"], atol=1e-5, rtol=0)
+    wide = tg.modules.SeqGAN_D(96, V).to(DEV)
+    with pytest.raises(RuntimeError, match="wider than"):
+        tg.ops.dis_score(wide, _t(seqs))
+
+
 def test_discriminator_unaligned_dropout_uniforms():
     """dropout uniforms that start 4 bytes into an allocation (a contiguous view): the 16-byte epilogue loads of the
     split highway cannot be used; the call must still match the oracle."""
@@ -910,11 +934,12 @@ def test_leak_reward_c1_shape_full_vs_oracle():
 
 @pytest.mark.parametrize("V,E,H,K,L,B,R,step", [(3, 32, 32, 16, 20, 1, 1, 4), (40, 32, 64, 8, 20, 3, 2, 5),
                                                 (150, 64, 128, 16, 24, 33, 1, 3), (9, 32, 32, 1, 20, 2, 3, 10),
-                                                (64, 48, 96, 5, 21, 5, 2, 7)])
+                                                (64, 48, 96, 5, 21, 5, 2, 7), (40009, 32, 32, 4, 20, 2, 1, 10)])
 def test_leak_reward_edge_shapes_against_oracle(V, E, H, K, L, B, R, step):
     """get_reward_leakgan on edge shapes: one sentence / one rollout, a three-word vocabulary, goal_size 1 and 5, hidden
     sizes up to the supported 128, embedding width off the 32 grid, step sizes that do not divide L (the reference then
-    scores L // step_size prefixes), batches off every tile size -- against the oracle, live dropout included."""
+    scores L // step_size prefixes), batches off every tile size, a vocabulary above 32 768 (the sampler's tile sums no
+    longer need the row's weights in LDS) -- against the oracle, live dropout included."""
     gsd = synth.leak_state(V, E, H, K, 1720, B, seed=V + L, std=0.2)
     dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=3)
     gen = tg.modules.load_numpy_state(tg.modules.LeakGAN_G(E, H, V, L, goal_size=K, step_size=step, batch_size=B), gsd, DEV)

@@ -226,24 +226,44 @@ def leak_weights(gen):
     return w, keep
 
 
+DIS_EMBED_DIM = 64   # kEd of csrc/tg_dis.hip: the scorer kernels' embedding width (the reference's cfg.dis_embed_dim)
+
+
+def _pad_last(d, width, name):
+    """[.., Ed] -> [.., 64] with zero columns: a narrower discriminator embedding (CNNDiscriminator takes any embed_dim,
+    models/discriminator.py:20-36) is the 64-wide one whose extra embedding columns and conv-weight columns are zero --
+    every window product gains only exact zeros, so the results are those of the Ed-wide scorer."""
+    pad = torch.zeros(d.shape[:-1] + (width,), dtype=torch.float32, device=d.device)
+    pad[..., :d.shape[-1]] = d
+    return pad, dev_ptr(pad, torch.float32, name)
+
+
 def dis_weights(dis, precision=None):
-    """Pack the live parameters of a CNNDiscriminator-shaped module (models/discriminator.py:30-36)."""
+    """Pack the live parameters of a CNNDiscriminator-shaped module (models/discriminator.py:30-36).  embed_dim 64
+    (the reference's default) is read in place; a narrower one is zero-padded to 64 per call; a wider one is refused."""
     keep = []
     w = DisW()
     w.precision = PRECISIONS[precision or default_dis_precision]
     d, w.emb = _param(dis.embeddings.weight, "embeddings.weight")
-    keep.append(d)
     V, Ed = d.shape
+    if Ed > DIS_EMBED_DIM:
+        raise RuntimeError("textgan_hip: discriminator embed_dim %d is wider than the %d the scorer kernels are built for"
+                           % (Ed, DIS_EMBED_DIM))
+    if Ed < DIS_EMBED_DIM:
+        d, w.emb = _pad_last(d, DIS_EMBED_DIM, "embeddings.weight")
+    keep.append(d)
     if len(dis.convs) > MAX_FILTERS:
         raise RuntimeError("textgan_hip: more than %d filter widths" % MAX_FILTERS)
     F = 0
     for k, conv in enumerate(dis.convs):
         cw, w.conv_w[k] = _param(conv.weight, "convs.%d.weight" % k)
         cb, w.conv_b[k] = _param(conv.bias, "convs.%d.bias" % k)
-        keep += [cw, cb]
         n, one, f, ed = cw.shape
         if one != 1 or ed != Ed:
             raise RuntimeError("textgan_hip: convs.%d.weight has shape %s, expected [n,1,f,%d]" % (k, tuple(cw.shape), Ed))
+        if Ed < DIS_EMBED_DIM:
+            cw, w.conv_w[k] = _pad_last(cw, DIS_EMBED_DIM, "convs.%d.weight" % k)
+        keep += [cw, cb]
         w.f[k], w.n[k] = f, n
         F += n
     w.n_filters = len(dis.convs)
@@ -254,7 +274,7 @@ def dis_weights(dis, precision=None):
     d, w.out_b = _param(dis.feature2out.bias, "feature2out.bias"); keep.append(d)
     if keep[-4].shape != (F, F) or keep[-2].shape != (n_out, F):
         raise RuntimeError("textgan_hip: discriminator parameter shapes are inconsistent")
-    w.V, w.Ed, w.F, w.n_out = V, Ed, F, n_out
+    w.V, w.Ed, w.F, w.n_out = V, DIS_EMBED_DIM, F, n_out
     return w, keep
 
 

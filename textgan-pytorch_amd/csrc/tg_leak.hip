@@ -133,11 +133,10 @@ __global__ __launch_bounds__(256) void k_leak_draw(LeakArgs a) {
     }
     extern __shared__ float lds[];
     const int Ls = a.Ls, GK = a.GK, NG = a.NG, NT = Ls / 16;
-    float* w = lds;                       // [8*Ls] weights, entries >= V are 0
-    float* ts = w + kNSpan * Ls;          // [8*NT] tile sums
+    float* ts = lds;                      // [8*NT] tile sums
     float* gs = ts + kNSpan * NT;         // [8*NG] group sums
-    double* ss = reinterpret_cast<double*>(gs + kNSpan * NG + ((kNSpan * NG) & 1));  // [8] span sums
-    float* red = reinterpret_cast<float*>(ss + kNSpan);                             // [256]
+    double* ss = reinterpret_cast<double*>(gs + kNSpan * NG + ((kNSpan * (NT + NG)) & 1));  // [8] span sums
+    float* red = reinterpret_cast<float*>(ss + kNSpan);                                    // [256]
     const float* lg = a.logits + (size_t)n * V;
     float m = TG_NEG_INF;
     for (int v = tid; v < V; v += 256) m = __builtin_fmaxf(m, lg[v]);
@@ -148,11 +147,12 @@ __global__ __launch_bounds__(256) void k_leak_draw(LeakArgs a) {
         __syncthreads();
     }
     m = red[0];
-    for (int v = tid; v < kNSpan * Ls; v += 256) w[v] = v < V ? tg_expf(lg[v] - m) : 0.f;
-    __syncthreads();
+    // weight of entry v: exp(logit - max), 0 past the vocabulary; evaluated where it is summed (the row's weights are
+    // not kept: 8*Ls floats of LDS were what limited V to 32 768) -- the same expression at every use, so the same bits
+    auto wgt = [&](int v) { return v < V ? tg_expf(lg[v] - m) : 0.f; };
     for (int q = tid; q < kNSpan * NT; q += 256) {   // tile q of the row: entries [16q, 16q+16)
         float s = 0.f;
-        for (int r = 0; r < 16; ++r) s += w[q * 16 + r];
+        for (int r = 0; r < 16; ++r) s += wgt(q * 16 + r);
         ts[q] = s;
     }
     __syncthreads();
@@ -212,7 +212,7 @@ __global__ __launch_bounds__(256) void k_leak_draw(LeakArgs a) {
     float pp = 0.f;
     int tk = t_hi - 1;
     for (int j = t_lo; j < t_hi; ++j) {
-        pp += w[j];
+        pp += wgt(j);
         if (p + (double)pp > target) { tk = j; break; }
     }
     a.out[orow + pos] = tk;
@@ -623,10 +623,10 @@ int check_leak(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, int 
             return TG_ERR_ARG;
         }
     }
-    if (g->H % 32 || g->H < 32 || g->H > kMaxHLeak || g->E < 1 || g->K < 1 || g->K > 64 || g->V < 1 || g->V > 32768 ||
+    if (g->H % 32 || g->H < 32 || g->H > kMaxHLeak || g->E < 1 || g->K < 1 || g->K > 64 || g->V < 1 || g->V > 65536 ||
         g->step_size < 1) {
         tg_set_error("tg_leak_rollout: shape V=%d E=%d H=%d K=%d step=%d not supported (H a multiple of 32 up to %d, "
-                     "goal_size <= 64, V <= 32768)", g->V, g->E, g->H, g->K, g->step_size, kMaxHLeak);
+                     "goal_size <= 64, V <= 65536)", g->V, g->E, g->H, g->K, g->step_size, kMaxHLeak);
         return TG_ERR_ARG;
     }
     if (g->G != d->F) {
@@ -707,7 +707,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     a.NG = (NT + a.GK - 1) / a.GK;
     const int H = g->H, K = g->K;
 
-    const size_t sm_draw = sizeof(float) * ((size_t)kNSpan * a.Ls + (size_t)kNSpan * NT + (size_t)kNSpan * a.NG + 2) +
+    const size_t sm_draw = sizeof(float) * ((size_t)kNSpan * NT + (size_t)kNSpan * a.NG + 2) +
                            sizeof(double) * kNSpan + sizeof(float) * 256;
     const size_t sm_cells = sizeof(float) * ((size_t)4 * H * 33 + (size_t)32 * (H + 1) + 2) +
                             sizeof(double) * ((size_t)32 * 8 + (size_t)32 * K);
