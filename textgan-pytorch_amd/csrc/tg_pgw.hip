@@ -653,6 +653,98 @@ void k_fgemm(const FgArgs a) {
     }
 }
 
+
+// Backward, split mode: one pass over a chunk of logits [rows, V] does what were four -- dlogits in place, two
+// fragment conversions, the bias gradient's column sums (2.9 GB of traffic per 3 264 x 32 000 chunk; this pass reads the
+// logits once and writes the fragments: 1.25 GB).  Workgroup = 32 rows x 128 vocabulary entries:
+//   d = coeff (1[v = target] - exp(logit - lse)) -> LDS (fp32), then
+//   B pieces of dlogits   (n = row, k = v):  [rb][kb = v/16][hi|lo][lane = row%32 + 32 (v/8 % 2)]      -> DLb3
+//   B pieces of dlogits^T (n = v, k = row):  [vb = v/32][kb = row/16][hi|lo][lane = v%32 + 32 (row/8 % 2)] -> DLb4
+//   part[rb][v] = sum of the block's 32 rows (summed over the blocks in order by k_colsum_final)
+constexpr int kDlV = 128;
+__global__ __launch_bounds__(256) void k_dl_frag(const float* __restrict__ logits, int V, int rows, long row0, int N, int L,
+                                                 const int64_t* __restrict__ target, const float* __restrict__ lse,
+                                                 const float* __restrict__ coeff, const float* __restrict__ scal,
+                                                 f16x8* __restrict__ DLb3, int KB3, f16x8* __restrict__ DLb4, int KB4,
+                                                 float* __restrict__ part) {
+    __shared__ float tile[32][kDlV + 1];
+    const int tid = threadIdx.x;
+    const int v0 = blockIdx.x * kDlV, rb = blockIdx.y;
+    __shared__ float r_lse[32], r_cf[32];
+    __shared__ int r_tg[32];
+    if (tid < 32) {
+        const int rl = rb * 32 + tid;
+        float ls = 0.f, cf = 0.f;
+        int tg = -1;
+        if (rl < rows) {
+            const long r = row0 + rl;
+            const long o = (long)(r % N) * L + (r / N);
+            ls = lse[o];
+            cf = coeff[o];
+            tg = (int)target[o];
+        }
+        r_lse[tid] = ls; r_cf[tid] = cf; r_tg[tid] = tg;
+    }
+    __syncthreads();
+    // element idx = tid + 256 i -> (row idx / 128, column idx % 128): a wave reads 256 contiguous bytes of one row
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int idx = tid + 256 * i, row = idx >> 7, col = idx & (kDlV - 1);
+        const int rl = rb * 32 + row, v = v0 + col;
+        float d = 0.f;
+        if (rl < rows && v < V)
+            d = r_cf[row] * ((v == r_tg[row] ? 1.f : 0.f) - tg_expf(logits[(long)rl * V + v] - r_lse[row]));
+        tile[row][col] = d;
+    }
+    __syncthreads();
+    const float sD = scal[3];
+    auto split8 = [&](const float (&x)[8], f16x8& h, f16x8& l) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float y = x[e] * sD;
+            const _Float16 hh = (_Float16)y;
+            h[e] = hh;
+            l[e] = (_Float16)(y - (float)hh);
+        }
+    };
+    // dlogits pieces: 8 k blocks x 64 lanes
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = tid + 256 * it, lane = q & 63, kbl = q >> 6;
+        const int kb = (v0 >> 4) + kbl;
+        if (kb < KB3) {
+            float x[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = tile[lane & 31][16 * kbl + 8 * (lane >> 5) + e];
+            f16x8 h, l;
+            split8(x, h, l);
+            f16x8* d = DLb3 + (((size_t)rb * KB3 + kb) * 2) * 64 + lane;
+            d[0] = h;
+            d[64] = l;
+        }
+    }
+    // dlogits^T pieces: 4 vocabulary blocks x 2 k blocks (16 rows each) x 64 lanes
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int q = tid + 256 * it, lane = q & 63, kbl = (q >> 6) & 1, vbl = q >> 7;
+        float x[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = tile[16 * kbl + 8 * (lane >> 5) + e][32 * vbl + (lane & 31)];
+        f16x8 h, l;
+        split8(x, h, l);
+        const size_t vb = (size_t)(v0 >> 5) + vbl;
+        f16x8* d = DLb4 + ((vb * KB4 + 2 * rb + kbl) * 2) * 64 + lane;
+        d[0] = h;
+        d[64] = l;
+    }
+    if (tid < kDlV && v0 + tid < V) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) sacc += tile[r][tid];
+        part[(size_t)rb * V + v0 + tid] = sacc;
+    }
+}
+
 // out[i] = sum_z part[z*zstride + i], z ascending (fixed order)
 __global__ __launch_bounds__(256) void k_sum_slices(const float* part, int nz, long zstride, long n, float* out) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -794,14 +886,21 @@ int fgemm(hipStream_t s, const void* Af, int MBp, const void* Bf, int KB, float*
 
 // k_gemm32 with the contraction cut over blockIdx.z when the output has too few tiles to fill the chip (the weight
 // gradients: [4H, E] from thousands of token rows): slices into zbuf [nz][M][N], summed in order into C (ldc == N).
+// k slices gemm_sliced cuts an M x N x K product into (1 = not cut); its zbuf needs sliced_nz * M * N floats
+int sliced_nz(long M, long N, long K) {
+    const long tiles = ((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM);
+    if (tiles <= 0) return 1;
+    long nz = 512 / tiles;
+    if (nz > kMaxSlices) nz = kMaxSlices;
+    if (nz > K / (8 * kBK)) nz = K / (8 * kBK);
+    return nz < 2 ? 1 : (int)nz;
+}
+
 template <bool AK, bool BK>
 void gemm_sliced(hipStream_t s, const float* A, long lda, const float* B, long ldb, float* C, int M, int N, int K,
                  float* zbuf, const int64_t* a_gather = nullptr, const int64_t* b_gather = nullptr, int gather_max = 0) {
     if (M <= 0 || N <= 0) return;
-    const long tiles = (long)((N + kBN - 1) / kBN) * ((M + kBM - 1) / kBM);
-    int nz = (int)(512 / tiles);
-    if (nz > kMaxSlices) nz = kMaxSlices;
-    if (nz > K / (8 * kBK)) nz = K / (8 * kBK);
+    int nz = sliced_nz(M, N, K);
     if (nz < 2) { gemm<AK, BK>(s, A, lda, B, ldb, C, N, M, N, K, nullptr, false, a_gather, b_gather, gather_max); return; }
     const int kslice = ((K + nz - 1) / nz + kBK - 1) / kBK * kBK;
     nz = (K + kslice - 1) / kslice;
@@ -964,9 +1063,16 @@ BwdLayout bwd_layout(const TgGenWeights* w, int N, int L, bool split) {
     o.whhT = take(sizeof(float) * (size_t)4 * H * H);    // W_hh^T
     o.dcn = take(sizeof(float) * (size_t)N * H);
     o.dX = take(sizeof(float) * (size_t)NL * E);
-    const size_t slabs_dl = (size_t)((rc + kSlab - 1) / kSlab) * V, slabs_da = (size_t)((NL + kSlab - 1) / kSlab) * 4 * H;
+    const size_t slabs_dl = (size_t)((rc + (split ? 32 : kSlab) - 1) / (split ? 32 : kSlab)) * V,
+                 slabs_da = (size_t)((NL + kSlab - 1) / kSlab) * 4 * H;
     o.part = take(sizeof(float) * (slabs_dl > slabs_da ? slabs_dl : slabs_da));
-    o.gz = take(sizeof(float) * (size_t)kMaxSlices * 4 * H * (E > H ? E : H));   // k slices of the weight-gradient GEMMs
+    {   // k slices of the weight-gradient GEMMs ([4H, E], [4H, H] over NL rows) and of dX [NL, E] (over 4H) when cut
+        size_t need = (size_t)sliced_nz(4 * H, E, NL) * 4 * H * E;
+        const size_t b = (size_t)sliced_nz(4 * H, H, NL) * 4 * H * H, c = (size_t)sliced_nz(NL, E, 4 * H) * NL * E;
+        need = need > b ? need : b;
+        need = need > c ? need : c;
+        o.gz = take(sizeof(float) * need);
+    }
     if (split) {
         o.split = take(split_fwd_layout(w, NL).total);
         o.Wa3 = take(fg_bytes(H, V));      // A(m = h, k = v) = W_out^T
@@ -1031,11 +1137,13 @@ int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* ta
             gemm<false, false>(s, hs + r0 * 2 * H, 2 * H, w->w_out, H, DL, V, rows, V, H, w->b_out);
             proj_end();
         }
-        hipLaunchKernelGGL(k_row_softmax, dim3(rows), dim3(256), 0, s, DL, (long)V, V, r0, N, L, target, nullptr, nullptr,
-                           lse, coeff);
         if (split) {
-            to_frag(s, DL, V, 1, rows, V, scal, 3, fg_rb(rc), fg_kb(V), ws + lo.DLb3);
-            to_frag(s, DL, 1, V, V, rows, scal, 3, fg_rb(V), fg_kb(rows), ws + lo.DLb4);
+            // dlogits, both fragment layouts and the bias gradient's partial sums in one pass over the logits
+            const int nrb = (rows + 31) / 32;
+            hipLaunchKernelGGL(k_dl_frag, dim3((V + kDlV - 1) / kDlV, nrb), dim3(256), 0, s, DL, V, rows, r0, N, L, target, lse,
+                               coeff, scal, reinterpret_cast<f16x8*>(ws + lo.DLb3), fg_kb(V),
+                               reinterpret_cast<f16x8*>(ws + lo.DLb4), fg_kb(rows), part);
+            hipLaunchKernelGGL(k_colsum_final, dim3(blocks(V)), dim3(256), 0, s, part, nrb, V, g->b_out, r0 > 0 ? 1 : 0);
             to_frag(s, hs + r0 * 2 * H, 1, 2 * H, H, rows, scal, 1, fg_rb(H), fg_kb(rows), ws + lo.Ha4);
             proj_begin(TG_KERNEL_PGW_PROJ_DH);
             if (int rc2 = fgemm(s, ws + lo.Wa3, fg_rb(H), ws + lo.DLb3, fg_kb(V), dhproj + r0 * H, H, H, rows, scal, 4, nullptr,
@@ -1045,13 +1153,15 @@ int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* ta
                                 r0 > 0)) return rc2;                                                           // dlogits^T . h
             proj_end();
         } else {
+            hipLaunchKernelGGL(k_row_softmax, dim3(rows), dim3(256), 0, s, DL, (long)V, V, r0, N, L, target, nullptr, nullptr,
+                               lse, coeff);
             proj_begin(TG_KERNEL_PGW_PROJ_DH);
             gemm<false, true>(s, DL, V, w->w_out, H, dhproj + r0 * H, H, rows, H, V);                 // dlogits . W_out
             proj_begin(TG_KERNEL_PGW_PROJ_DW);
             gemm<true, true>(s, DL, V, hs + r0 * 2 * H, 2 * H, g->w_out, H, V, H, rows, nullptr, r0 > 0);  // dlogits^T . h
             proj_end();
+            colsum(s, DL, (long)V, (long)rows, V, part, g->b_out, r0 > 0);
         }
-        colsum(s, DL, (long)V, (long)rows, V, part, g->b_out, r0 > 0);
     }
     // ---- back through time: the pre-activations of every position from two batched GEMMs (all h_{t-1} are saved
     // states), then one launch per position: dh = dh_proj + da_{t+1} W_hh and the cell's gate gradients
@@ -1073,7 +1183,7 @@ int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* ta
     gemm_sliced<true, true>(s, DA, 4 * H, states, 2 * H, g->w_hh, 4 * H, H, (int)NL, gz);                         // DA^T . H_prev
     colsum(s, DA, (long)4 * H, NL, 4 * H, part, g->b_ih, false);
     hipLaunchKernelGGL(k_copy, dim3(blocks(4 * H)), dim3(256), 0, s, g->b_ih, g->b_hh, (long)4 * H);
-    gemm<false, true>(s, DA, 4 * H, w->w_ih, E, dX, E, (int)NL, E, 4 * H);                                       // DA . W_ih
+    gemm_sliced<false, true>(s, DA, 4 * H, w->w_ih, E, dX, (int)NL, E, 4 * H, gz);                                // DA . W_ih
     hipLaunchKernelGGL(k_zero, dim3(1024), dim3(256), 0, s, g->emb, (long)V * E);
     hipLaunchKernelGGL(k_scatter_emb, dim3(blocks(NL * E)), dim3(256), 0, s, dX, idx, NL, E, V, padding_idx, g->emb);
     tg_prof_end(s);
