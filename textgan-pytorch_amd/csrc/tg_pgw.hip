@@ -228,25 +228,42 @@ __global__ __launch_bounds__(kStepThreads) void k_lstm_step_fwd(const float* __r
     const int g = w & 3, kh = w >> 2;
     const int nc = H >> 5, half = (nc + 1) >> 1;
     const int nrow = n0 + i < N ? n0 + i : N - 1;
+    // the element-wise part's own operands are fetched first, so their round trip runs under the contraction
+    constexpr int NP = (T * T + kStepThreads - 1) / kStepThreads;   // (unit, row) pairs per thread: 2 or 1
+    float e_pre[NP][4], e_c[NP];
+    bool e_ok[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int p = tid + kStepThreads * q, u = p % T, nl = p / T, n = n0 + nl;
+        e_ok[q] = p < T * T && n < N;
+        e_c[q] = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) e_pre[q][gg] = 0.f;
+        if (e_ok[q]) {
+            const size_t row = (size_t)t * N + n;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) {
+                const int col = gg * H + u0 + u;
+                e_pre[q][gg] = preX[row * 4 * H + col] + (b_ih[col] + b_hh[col]);
+            }
+            e_c[q] = states[row * 2 * H + H + u0 + u];
+        }
+    }
     typename StepAcc<T>::type acc = {};
     step_dot<T>(acc, w_hh + (size_t)(g * H + u0 + i) * H, states + ((size_t)t * N + nrow) * 2 * H, kg,
                 kh ? half : 0, kh ? nc : half);
     step_spill<T>(acc, part[w], i, kg);
     __syncthreads();
-    for (int p = tid; p < T * T; p += kStepThreads) {
-        const int u = p % T, nl = p / T, n = n0 + nl;
-        if (n >= N) continue;
-        const size_t row = (size_t)t * N + n;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        if (!e_ok[q]) continue;
+        const int p = tid + kStepThreads * q, u = p % T, nl = p / T, n = n0 + nl;
         float gate[4];
 #pragma unroll
-        for (int gg = 0; gg < 4; ++gg) {
-            const int col = gg * H + u0 + u;
-            gate[gg] = (part[gg][u][nl] + part[4 + gg][u][nl]) + preX[row * 4 * H + col] + (b_ih[col] + b_hh[col]);
-        }
+        for (int gg = 0; gg < 4; ++gg) gate[gg] = (part[gg][u][nl] + part[4 + gg][u][nl]) + e_pre[q][gg];
         const float ig = tg_sigmoid(gate[0]), fg = tg_sigmoid(gate[1]), gc = tg_tanh(gate[2]), og = tg_sigmoid(gate[3]);
-        const float* prev = states + row * 2 * H;
         float* cur = states + ((size_t)(t + 1) * N + n) * 2 * H;
-        const float cn = fg * prev[H + u0 + u] + ig * gc;
+        const float cn = fg * e_c[q] + ig * gc;
         cur[H + u0 + u] = cn;
         cur[u0 + u] = og * tg_tanh(cn);
     }
@@ -263,6 +280,29 @@ __global__ __launch_bounds__(kStepThreads) void k_lstm_step_bwd(const float* __r
     __shared__ float part[8][T][T + 1];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane % T, kg = lane / T;
     const int u0 = T * blockIdx.x, n0 = T * blockIdx.y;
+    // the element-wise part's own operands first: their round trip runs under the contraction
+    constexpr int NP = (T * T + kStepThreads - 1) / kStepThreads;
+    float e_g[NP][4], e_dh[NP], e_cp[NP], e_ct[NP], e_dc[NP];
+    bool e_ok[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const int p = tid + kStepThreads * q, u = p % T, nl = p / T, n = n0 + nl;
+        e_ok[q] = p < T * T && n < N;
+        e_dh[q] = e_cp[q] = e_ct[q] = e_dc[q] = 0.f;
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg) e_g[q][gg] = 0.f;
+        if (e_ok[q]) {
+            const size_t row = (size_t)t * N + n;
+            const int uu = u0 + u;
+            const float* gp = P + row * 4 * H;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) e_g[q][gg] = gp[gg * H + uu] + (b_ih[gg * H + uu] + b_hh[gg * H + uu]);
+            e_dh[q] = dhproj[row * H + uu];
+            e_cp[q] = states[row * 2 * H + H + uu];
+            e_ct[q] = states[((size_t)(t + 1) * N + n) * 2 * H + H + uu];
+            e_dc[q] = last ? 0.f : dcn[(size_t)n * H + uu];
+        }
+    }
     if (!last) {
         const int nc = (4 * H) >> 5;                    // a multiple of 4
         const int c0 = (int)((long)nc * w / 8), c1 = (int)((long)nc * (w + 1) / 8);
@@ -272,30 +312,25 @@ __global__ __launch_bounds__(kStepThreads) void k_lstm_step_bwd(const float* __r
         step_spill<T>(acc, part[w], i, kg);
         __syncthreads();
     }
-    for (int p = tid; p < T * T; p += kStepThreads) {
-        const int u = p % T, nl = p / T, n = n0 + nl;
-        if (n >= N) continue;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        if (!e_ok[q]) continue;
+        const int p = tid + kStepThreads * q, u = p % T, nl = p / T, n = n0 + nl;
         const size_t row = (size_t)t * N + n;
         const int uu = u0 + u;
-        float dh = dhproj[row * H + uu];
+        float dh = e_dh[q];
         if (!last) {
             float sdot = part[0][u][nl];
 #pragma unroll
             for (int ww = 1; ww < 8; ++ww) sdot += part[ww][u][nl];
             dh += sdot;
         }
-        const float* gp = P + row * 4 * H;
-        const float ig = tg_sigmoid(gp[uu] + (b_ih[uu] + b_hh[uu]));
-        const float fg = tg_sigmoid(gp[H + uu] + (b_ih[H + uu] + b_hh[H + uu]));
-        const float gg = tg_tanh(gp[2 * H + uu] + (b_ih[2 * H + uu] + b_hh[2 * H + uu]));
-        const float og = tg_sigmoid(gp[3 * H + uu] + (b_ih[3 * H + uu] + b_hh[3 * H + uu]));
-        const float cprev = states[row * 2 * H + H + uu];
-        const float ct = states[((size_t)(t + 1) * N + n) * 2 * H + H + uu];
-        const float tc = tg_tanh(ct);
-        const float dc = (last ? 0.f : dcn[(size_t)n * H + uu]) + dh * og * (1.f - tc * tc);
+        const float ig = tg_sigmoid(e_g[q][0]), fg = tg_sigmoid(e_g[q][1]), gg = tg_tanh(e_g[q][2]), og = tg_sigmoid(e_g[q][3]);
+        const float tc = tg_tanh(e_ct[q]);
+        const float dc = e_dc[q] + dh * og * (1.f - tc * tc);
         float* da = DA + row * 4 * H;
         da[uu] = dc * gg * ig * (1.f - ig);
-        da[H + uu] = dc * cprev * fg * (1.f - fg);
+        da[H + uu] = dc * e_cp[q] * fg * (1.f - fg);
         da[2 * H + uu] = dc * ig * (1.f - gg * gg);
         da[3 * H + uu] = dh * tc * og * (1.f - og);
         dcn[(size_t)n * H + uu] = dc * fg;
