@@ -60,6 +60,9 @@ struct ConvArgs {
     float* cv;            // StoreAll: [N,L,F] out; Prefix: running max over time of the sentences' windows, in
     int B;                // Prefix: sentences per (i, g) block
     int N, L;
+    int valid_len;        // positions t >= valid_len are read as token 0 (padding) whatever seqs holds there; Plain
+                          // mode evaluates the windows that start below it only and takes the others, all padding,
+    const float* padpool; // from here: [F] pooled features of an all-padding sequence (null: valid_len == L)
     int S, log2S;         // sequences per workgroup (power of two <= 32), TT = 32 / S
     int n_items;
     int foff[TG_MAX_FILTERS];  // feature offset of each width
@@ -190,7 +193,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 const int ts = idx >> 4;          // t*S + s
                 const int sq = ts & (S - 1), t = ts >> log2S;
                 const int seq = tg_min(seq0 + sq, a.N - 1);
-                tok[j] = (int)a.seqs[(size_t)seq * L + t];
+                tok[j] = t < a.valid_len ? (int)a.seqs[(size_t)seq * L + t] : 0;
             }
 #pragma unroll
             for (int j = 0; j < kGB; ++j) {
@@ -257,6 +260,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         const int f = merged ? a.mfmax[mt] : a.w.f[k];
         const int nk = merged ? 32 : a.w.n[k];
         const int K = f * kEd, T = L - (merged ? a.mfmin[mt] : f) + 1;
+        const int Tv = (MODE == kConvPlain) ? tg_min(T, a.valid_len) : T;   // windows evaluated here: t < Tv
         const int arow = tg_min(mt * 32 + n, nk - 1);
         const float* wp = merged ? nullptr : a.w.conv_w[k] + (size_t)arow * K + 32 * hh;
         const MergedMeta* mm = merged ? a.mmeta + mt : nullptr;
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         // windows t <= g - f lie inside the shared prefix (Prefix mode): tiles start at the first fresh window of the
         // workgroup's smallest given_num, not at a multiple of the tile's time span
         const int t_org = (MODE == kConvPrefix) ? tg_max(0, g_min - f + 1) : 0;
-        const int ntile = tg_max(0, T - t_org + TT - 1) >> (5 - log2S);  // ceil((T - t_org) / TT), 0 if none is fresh
+        const int ntile = tg_max(0, Tv - t_org + TT - 1) >> (5 - log2S);  // ceil((Tv - t_org) / TT), 0 if none is fresh
 
         float runmax[16];
 #pragma unroll
@@ -285,7 +289,7 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int tw = t_org + (nb0 + nt) * TT + tsub;
-                const bool ok = (nt < nbc) && (tw < T);
+                const bool ok = (nt < nbc) && (tw < Tv);
                 if (merged) {  // per-row width: position tw exists for row r iff tw + fw <= L
                     if (MODE == kConvStoreAll) {
                         if (ok && seq0 + s < a.N) {
@@ -426,8 +430,10 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
         const int fo = merged ? 0 : a.foff[k];
         const float* pb = merged ? nullptr : a.w.conv_b[k];
         // Prefix mode: max over the windows t <= g - f (bias included) of the base sentence
+        // Plain mode with windows left out (all padding): their value, the same for every sequence
         const float* pm = (!merged && MODE == kConvPrefix && g_lane >= f)
-                              ? a.cv + ((size_t)b_lane * L + (g_lane - f)) * a.w.F + fo : nullptr;
+                              ? a.cv + ((size_t)b_lane * L + (g_lane - f)) * a.w.F + fo
+                              : (!merged && MODE == kConvPlain && a.padpool && Tv < T) ? a.padpool + fo : nullptr;
         const bool aligned = ((fo | a.w.F) & 3) == 0 && (reinterpret_cast<uintptr_t>(pb) & 15) == 0;
         auto quad_vec = [&](int rq) __attribute__((always_inline)) {   // this lane's quad rq goes the 16-byte way
             return act && aligned && mt * 32 + 8 * rq + 4 * hh + 4 <= nk;
@@ -483,6 +489,8 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                     float o = __builtin_fmaxf(runmax[r] + mm->bias[mrow(r)], 0.f);
                     if (MODE == kConvPrefix && g_lane >= fwr)
                         o = __builtin_fmaxf(o, a.cv[((size_t)b_lane * L + (g_lane - fwr)) * a.w.F + ft]);
+                    if (MODE == kConvPlain && a.padpool && a.valid_len < L - fwr + 1)
+                        o = __builtin_fmaxf(o, a.padpool[ft]);
                     if (SPLIT && a.pfrag) pf_store1(a.pfrag, a.KBp, seq0 + s, ft, o, sP);
                     else po[ft] = o;
                 }
@@ -1290,7 +1298,8 @@ MergePlan plan_merge(const TgDisWeights* w) {
     return pl;
 }
 
-int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem, int min_S = 1) {
+int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem, int min_S = 1, int valid_len = -1) {
+    const int vl = valid_len < 0 ? L : valid_len;   // windows per width: min(L - f + 1, vl)
     ca.w = *w;
     ca.L = L;
     ca.stamps = tg_diag_pointer("TG_CONV_STAMPS");
@@ -1322,7 +1331,7 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
                 tg_set_error("tg_dis_score: too many filter tiles (> %d)", kMaxItems);
                 return TG_ERR_ARG;
             }
-            tmp[ni].k = k; tmp[ni].mt = mt; tmp[ni].cost = (long)w->f[k] * (L - w->f[k] + 1);
+            tmp[ni].k = k; tmp[ni].mt = mt; tmp[ni].cost = (long)w->f[k] * tg_min_host(L - w->f[k] + 1, vl);
             ++ni;
         }
     }
@@ -1333,7 +1342,7 @@ int prepare_conv(ConvArgs& ca, const TgDisWeights* w, int N, int L, size_t* smem
         }
         ca.mfmax[m] = pl.tile[m].fmax;
         ca.mfmin[m] = pl.tile[m].fmin;
-        tmp[ni].k = 0xFF; tmp[ni].mt = m; tmp[ni].cost = (long)pl.tile[m].fmax * (L - pl.tile[m].fmin + 1);
+        tmp[ni].k = 0xFF; tmp[ni].mt = m; tmp[ni].cost = (long)pl.tile[m].fmax * tg_min_host(L - pl.tile[m].fmin + 1, vl);
         ++ni;
     }
     for (int i = 1; i < ni; ++i) {  // insertion sort, heaviest first
@@ -1403,7 +1412,8 @@ size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
     return align256(pooled_bytes(w, N)) + align256(sizeof(float) * (size_t)N * hw_nchunk(w) * kMaxOut) +
            align256(sizeof(float) * (size_t)B_prefix * L * w->F) +
            align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256 +
-           align256(hw_weight_bytes(w));
+           align256(hw_weight_bytes(w)) +
+           align256(sizeof(float) * w->F) + align256(sizeof(int64_t) * L);   // tg_dis_features: padpool, L padding tokens
 }
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
@@ -1503,7 +1513,9 @@ int launch_highway_frag(Hw2Args& a, int MBp, int N, hipStream_t stream) {
 // sentences != nullptr: seqs is [R,L,B,L] rollout completions (N = R*L*B), prefix reuse.
 int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const int64_t* sentences, int B, int col,
                float dropout_p, const float* dropout_uniforms, float* reward_out, float* logits_out,
-               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream, bool reuse = false) {
+               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream, bool reuse = false,
+               int valid_len = -1, int N_layout = -1) {
+    const int NL = N_layout < N ? N : N_layout;   // sequences the workspace is laid out for
     if (N < 0 || L < 1 || (N > 0 && !seqs)) {   // an empty batch is a no-op
         tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
@@ -1519,24 +1531,27 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;
-    const size_t need = ws_bytes(w, N, L, sentences ? B : 0);
+    const size_t need = ws_bytes(w, NL, L, sentences ? B : 0);
     if (!workspace || workspace_bytes < need) {
         tg_set_error("tg_dis_score: workspace too small (%zu < %zu)", workspace_bytes, need);
         return TG_ERR_WORKSPACE;
     }
     float* pooled = (float*)workspace;
     const int nchunk = (w->F + kHwTile - 1) / kHwTile;   // fp32 highway; the fragment highway sets its own count
-    float* partial = (float*)((char*)workspace + align256(pooled_bytes(w, N)));
-    float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)N * hw_nchunk(w) * kMaxOut));
+    float* partial = (float*)((char*)workspace + align256(pooled_bytes(w, NL)));
+    float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)NL * hw_nchunk(w) * kMaxOut));
     _Float16* w16 = (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
     void* scal = (char*)w16 + align256(2 * sizeof(_Float16) * conv_weight_count(w));
     _Float16* hw16 = (_Float16*)((char*)scal + 256);
+    float* padpool = (float*)((char*)hw16 + align256(hw_weight_bytes(w)));
+    int64_t* padtok = (int64_t*)((char*)padpool + align256(sizeof(float) * w->F));
 
     // ---- conv
     ConvArgs ca = {};
     size_t sm = 0;
-    rc = prepare_conv(ca, w, sentences ? B : N, L, &sm, sentences ? 1 : 8);
+    rc = prepare_conv(ca, w, sentences ? B : N, L, &sm, sentences ? 1 : 8, valid_len);
     if (rc) return rc;
+    ca.valid_len = valid_len < 0 ? L : valid_len;
     if (w->precision == TG_DIS_SPLIT_F16) {
         rc = prepare_split(ca, w, w16, scal, stream, reuse);
         if (rc) return rc;
@@ -1566,7 +1581,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
             hipLaunchKernelGGL(k_hw_make_frag, dim3(1024), dim3(256), 0, stream, w->hw_w, w->F, MBp, KB, scales,
                                reinterpret_cast<f16x8*>(hw16));
             hipLaunchKernelGGL(k_pf_zero_pad, dim3(256), dim3(256), 0, stream, reinterpret_cast<f16x8*>(pooled),
-                               (int)hw_rb(N), KB, w->F);
+                               (int)hw_rb(NL), KB, w->F);
             tg_prof_end(stream);
         }
         ca.pfrag = reinterpret_cast<_Float16*>(pooled);
@@ -1584,6 +1599,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         tg_prof_end(stream);
         rc = prepare_conv(ca, w, N, L, &sm, 8);
         if (rc) return rc;
+        ca.valid_len = L;
         ca.seqs = seqs;
         ca.pooled = pooled;
         ca.cv = cv;
@@ -1591,6 +1607,30 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         ca.B = B;
         rc = launch_conv<kConvPrefix>(ca, sm, stream);
     } else {
+        if (valid_len >= 0) {
+            // tg_dis_features: the windows that start at or behind valid_len are all padding and the same for every
+            // sequence -- their pooled value comes from one pass over a single all-padding sequence (same kernel, same
+            // arithmetic, so the features are the bits a pass over all windows gives), once per prepared workspace
+            if (!reuse) {
+                ConvArgs cp = ca;
+                size_t smp = 0;
+                rc = prepare_conv(cp, w, 1, L, &smp, 8);
+                if (rc) return rc;
+                if (hipMemsetAsync(padtok, 0, sizeof(int64_t) * L, stream) != hipSuccess) {
+                    tg_set_error("hipMemsetAsync failed");
+                    return TG_ERR_LAUNCH;
+                }
+                cp.seqs = padtok;
+                cp.N = 1;
+                cp.valid_len = L;
+                cp.padpool = nullptr;
+                cp.pfrag = nullptr;      // fp32 [1, F]
+                cp.pooled = padpool;
+                rc = launch_conv<kConvPlain>(cp, smp, stream);
+                if (rc) return rc;
+            }
+            ca.padpool = padpool;
+        }
         ca.seqs = seqs;
         ca.pooled = pooled;
         ca.N = N;
@@ -1638,7 +1678,15 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         tg_prof_end(stream);
     }
 
-    // ---- final: fixed-order partial sum, softmax column
+    // ---- final: fixed-order partial sum, softmax column (nothing to write when only the features are asked for)
+    if (!reward_out && !logits_out) {
+        hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) {
+            tg_set_error("tg_dis_score launch: %s", hipGetErrorString(e0));
+            return TG_ERR_LAUNCH;
+        }
+        return TG_OK;
+    }
     FinalArgs fa = {};
     fa.partial = partial;
     fa.out_b = w->out_b;
@@ -1794,12 +1842,17 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
                       feature_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
-// get_feature for the LeakGAN rollout's position loop (tg_leak.hip): tg_dis_score restricted to feature_out, with
+// get_feature for the LeakGAN rollout's position loop (tg_leak.hip): tg_dis_score restricted to feature_out, reading
+// the tokens at positions >= valid_len as padding (token 0), with
 // `reuse` = the workspace already holds this call's prepared weights (same w, same N as the call that wrote them).
-int tg_dis_features(const TgDisWeights* w, const int64_t* seqs, int N, int L, float* feature_out, void* workspace,
-                    size_t workspace_bytes, bool reuse, hipStream_t stream) {
+int tg_dis_features(const TgDisWeights* w, const int64_t* seqs, int N, int N_layout, int L, int valid_len,
+                    float* feature_out, void* workspace, size_t workspace_bytes, bool reuse, hipStream_t stream) {
+    if (valid_len < 0 || valid_len > L || N_layout < N) {
+        tg_set_error("tg_dis_features: valid_len %d outside [0, %d] or N_layout %d < N %d", valid_len, L, N_layout, N);
+        return TG_ERR_ARG;
+    }
     return score_impl(w, seqs, N, L, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, feature_out, workspace,
-                      workspace_bytes, stream, reuse);
+                      workspace_bytes, stream, reuse, valid_len, N_layout);
 }
 
 extern "C" size_t tg_dis_score_rollout_workspace_bytes(const TgDisWeights* w, int B, int L, int R) {

@@ -3,13 +3,26 @@
 // and the discriminator's get_feature (models/discriminator.py:51-64) -- gfx950 only.
 //
 // All rows (rollout index i, given_num index t, sentence b) advance one position together; per position:
-//   k_leak_draw   token of the position: the sentence's (pos < given_num) or the canonical inverse-CDF draw from the
-//                 previous position's outputs; written to the completions and to the zero-padded feature input
+//   k_leak_draw    token of the position: the sentence's (pos < given_num) or the canonical inverse-CDF draw from the
+//                  previous position's outputs; written to the completions and to the feature extractor's input
+//   k_leak_worker  worker LSTM cell (token embedding) and the projection operand z = temperature * [rg (x) h_w | rg]
+//   k_leak_proj    outputs[n, v] = z[n, :] . [work2goal.weight[v*K..v*K+K, :] | work2goal.bias[v*K..]]  (fp32 MFMA)
+// and, beside that chain:
 //   tg_dis_features  the scorer's get_feature over the rows' tokens so far (tg_dis.hip: conv + max-pool + highway on
-//                 the matrix cores, weights prepared once per call)
-//   k_leak_cells  worker LSTM cell (token embedding), the projection operand z = temperature * [rg (x) h_w | rg],
-//                 manager LSTM cell (feature), the goal bookkeeping
-//   k_leak_proj   outputs[n, v] = z[n, :] . [work2goal.weight[v*K..v*K+K, :] | work2goal.bias[v*K..]]  (fp32 MFMA)
+//                  the matrix cores, weights prepared once per call and workspace)
+//   k_leak_mgates, k_leak_manager  manager LSTM cell (feature), the goal bookkeeping
+//
+// Streams.  The manager's side reaches the tokens only through the real goal rg, which is rebuilt every step_size
+// positions (utils/rollout.py:89-93); between two rebuilds the tokens' chain draw -> worker -> proj -> draw needs
+// nothing from it, and the feature passes of different positions need nothing from each other (only the manager's
+// cells are a chain).  At run_leakgan.py's shape every kernel here is a few dozen workgroups -- latency, not
+// throughput -- so the call spreads over four streams: the caller's (tokens' chain), two of the device's own for the
+// feature passes of even and odd positions (each with its own scorer workspace and feature buffer), one for the
+// manager's cells; events order them (draw(pos) -> feature(pos) -> manager(pos) -> worker(pos + 1) where pos rebuilt
+// the goal; manager(pos - 2) -> feature(pos) for the buffers).  rg is a pair of buffers (the one in force, the one being
+// rebuilt) and the feature pass reads positions > pos as padding by argument, so no stream reads what another is
+// writing.  Manager passes behind the last rebuild that a worker pass still reads are not run.  Results do not depend
+// on the spread: TG_LEAK_ONE_STREAM=1 puts everything on the caller's stream (same bits, for timing comparisons).
 //
 // Goal algebra.  The reference keeps cur_goal = normalize(mana2goal(h_m)) (G = 1720 values per row and position)
 // and uses it only through rg = normalize(goal2goal(real_goal)), real_goal = a sum of four cur_goals (+ goal_init).
@@ -17,7 +30,10 @@
 // [K,H], q = W_g2g b_m2g and  ||W h_m + b||^2 = h_m^T Q h_m + 2 c^T h_m + s  (Q = W^T W, c = W^T b, s = b^T b): per
 // row and position K + 1 numbers instead of G.  P, q, Q, c, s and goal2goal(goal_init[b]) are computed once per call
 // and evaluated in fp64 (no cancellation worry, more accurate than the reference's fp32 sums).
+#include <stdlib.h>
+
 #include <mutex>
+#include <vector>
 
 #include "tg_common.h"
 #include "tg_dis.h"
@@ -29,6 +45,16 @@ constexpr int kLThreads = 256;
 constexpr int kMaxT = 64;       // given_num values per call
 constexpr int kNSpan = 8;       // canonical sampler: spans per row
 constexpr int kMaxHLeak = 128;
+constexpr int kMaxDevices = 64;
+
+// per device: the three side streams of a call (feature passes of even / odd positions, manager cells) and the events
+// that order them against each other and the caller's stream
+struct LeakSide {
+    hipStream_t stream[3] = {nullptr, nullptr, nullptr};
+    std::vector<hipEvent_t> ev;
+};
+std::mutex g_side_mu;
+LeakSide g_side[kMaxDevices];
 
 struct LeakArgs {
     TgLeakWeights w;
@@ -40,24 +66,36 @@ struct LeakArgs {
     int64_t* tok;              // [N]   token fed at this position
     float* feat;               // [N,G]
     float *hw, *cw, *hm, *cm;  // [N,H]
-    float* rg;                 // [N,K] normalised goal2goal(real_goal) in force
+    const float* rg_rd;        // [N,K] normalised goal2goal(real_goal) in force at this position (k_leak_worker reads)
+    float* rg_wr;              // [N,K] the other half of the pair: k_leak_manager writes the next one there
     double* ring;              // [4][N][K] goal2goal(cur_goal) of the last four positions
     float* z;                  // [N, K*H + K] projection operand
     float* mpre;               // [N, 4H] manager.weight_ih . feature of this position (k_leak_mgates)
     float* logits;             // [N,V]
     const double* prep;        // P [K*H], q [K], Q [H*H], c [H], s [1], gp [B*K]
     int given[kMaxT];
-    int B, L, T, i_lo, N, n0;  // N rows of this chunk, first row n0 = (i_chunk - i_lo) * T * B ... see row_ids
-    int i0;                    // first rollout index of the chunk
+    int order[kMaxT];          // the given_num indices in ascending order of given_num: order[rank] = t
+    int B, L, T, i_lo;
+    int N;                     // rows that take part at this position (a prefix of the chunk's rows, see row_ids)
+    int Nmax;                  // rows of the chunk: B + ni * T * B
+    int i0, ni;                // first rollout index of the chunk, number of them
     int pos;
     int Ls, GK, NG;            // canonical sampler geometry
     long long* stamps;         // diagnostic (TG_LEAK_STAMPS, -DTG_DIAG=1): k_leak_cells phase cycles, [workgroup][8]
 };
 
+// Rows of a chunk.  Until its given_num a row is fed its sentence and nothing it computes depends on its rollout index
+// or on which given_num it belongs to, so that part is computed once per sentence: rows 0 .. B-1 are the LEADERS, one
+// per sentence, fed the sentence at every position (t = -1).  Behind them the (given_num, rollout index, sentence) rows
+// with the given_nums in ascending order: a row joins at pos == given_num -- its state copied from its leader
+// (k_leak_fork), its first draw taken from the leader's outputs -- so the rows taking part at a position are a
+// prefix of the array (run_leakgan.py's shape: 13 900 row-steps per call instead of 24 300).
 __device__ __forceinline__ void row_ids(const LeakArgs& a, int n, int& i, int& t, int& b) {
-    b = n % a.B;
-    t = (n / a.B) % a.T;
-    i = a.i0 + n / (a.B * a.T);
+    if (n < a.B) { b = n; t = -1; i = a.i0; return; }
+    const int m = n - a.B;
+    b = m % a.B;
+    i = a.i0 + (m / a.B) % a.ni;
+    t = a.order[m / (a.B * a.ni)];
 }
 
 // ---- once per call: the goal algebra's constants, fp64
@@ -90,54 +128,155 @@ __global__ __launch_bounds__(64) void k_leak_prep(TgLeakWeights w, int B, double
     if (lane == 0) prep[idx] = acc;
 }
 
-// ---- per chunk: zero state, zero-padded feature input, rg = normalize(goal2goal(goal_init[b]))
+// ---- per chunk.  Leaders: zero state, zero-padded feature input, rg = normalize(goal2goal(goal_init[b])).  The other
+// rows: the sentence's first given_num tokens in the completions and in the feature input (their state arrives with
+// k_leak_fork).
 __global__ __launch_bounds__(256) void k_leak_init(LeakArgs a) {
     const int n = blockIdx.x;
-    const int H = a.w.H, K = a.w.K;
+    const int H = a.w.H, K = a.w.K, L = a.L;
     int i, t, b;
     row_ids(a, n, i, t, b);
+    if (t >= 0) {
+        const size_t orow = (((size_t)i * a.T + t) * a.B + b) * L;
+        for (int p = threadIdx.x; p < L; p += 256) {
+            const bool given = p < a.given[t];
+            const int64_t tk = given ? a.sentences[(size_t)b * L + p] : 0;
+            if (given) a.out[orow + p] = tk;
+            a.fed[(size_t)n * L + p] = tk;
+        }
+        return;
+    }
     for (int h = threadIdx.x; h < H; h += 256) {
         a.hw[(size_t)n * H + h] = 0.f; a.cw[(size_t)n * H + h] = 0.f;
         a.hm[(size_t)n * H + h] = 0.f; a.cm[(size_t)n * H + h] = 0.f;
     }
-    for (int p = threadIdx.x; p < a.L; p += 256) a.fed[(size_t)n * a.L + p] = 0;
-    for (int q = threadIdx.x; q < 4 * K; q += 256) a.ring[((size_t)(q / K) * a.N + n) * K + q % K] = 0.0;
+    for (int p = threadIdx.x; p < L; p += 256) a.fed[(size_t)n * L + p] = 0;
+    for (int q = threadIdx.x; q < 4 * K; q += 256) a.ring[((size_t)(q / K) * a.Nmax + n) * K + q % K] = 0.0;
     if (threadIdx.x == 0) {
         const double* gp = a.prep + K * H + K + H * H + H + 1 + (size_t)b * K;
         double ss = 0.0;
         for (int k = 0; k < K; ++k) ss += gp[k] * gp[k];
         double nrm = sqrt(ss);
         nrm = nrm < 1e-12 ? 1e-12 : nrm;
-        for (int k = 0; k < K; ++k) a.rg[(size_t)n * K + k] = (float)(gp[k] / nrm);
+        for (int k = 0; k < K; ++k) a.rg_wr[(size_t)n * K + k] = (float)(gp[k] / nrm);
+    }
+}
+
+// ---- rows [first, first + gridDim.x) reach their given_num at this position: the state their leaders hold after the
+// position before.  which 0 (caller's stream, before the draw): worker h, c and the goal in force (rg_wr = the buffer
+// rg_rd points into, for this launch); which 1 (manager's stream, before the manager pass): manager h, c, goal ring.
+__global__ __launch_bounds__(256) void k_leak_fork(LeakArgs a, int first, int which) {
+    const int n = first + blockIdx.x, b = (n - a.B) % a.B;
+    const int H = a.w.H, K = a.w.K, tid = threadIdx.x;
+    if (which == 0) {
+        for (int h = tid; h < H; h += 256) {
+            a.hw[(size_t)n * H + h] = a.hw[(size_t)b * H + h];
+            a.cw[(size_t)n * H + h] = a.cw[(size_t)b * H + h];
+        }
+        for (int k = tid; k < K; k += 256) a.rg_wr[(size_t)n * K + k] = a.rg_rd[(size_t)b * K + k];
+    } else {
+        for (int h = tid; h < H; h += 256) {
+            a.hm[(size_t)n * H + h] = a.hm[(size_t)b * H + h];
+            a.cm[(size_t)n * H + h] = a.cm[(size_t)b * H + h];
+        }
+        for (int q = tid; q < 4 * K; q += 256) {
+            double* slot = a.ring + (size_t)(q / K) * a.Nmax * K + q % K;
+            slot[(size_t)n * K] = slot[(size_t)b * K];
+        }
     }
 }
 
 // ---- token of position a.pos for every row (one workgroup per row)
-// pos < given_num: the sentence's token.  Otherwise the canonical inverse-CDF draw (DESIGN.md section 4;
+// A leader: the sentence's token.  Any other row (pos >= given_num, or it would not take part): the canonical inverse-CDF draw (DESIGN.md section 4;
 // oracle/textgan_oracle.c canonical_draw) from w[v] = exp(logits[n,v] - max): tile sums and group sums fp32
 // sequential, span sums / total / target / every prefix comparison fp64.
+//
+// CELL: the worker's pass of the position for the same row follows in the same workgroup (k_leak_worker's work on the
+// vector units: a launch less per position on the chain the tokens wait for; chosen by the host when the cell's weights
+// are small, see tg_leak_rollout).  Gate pre-activations in the oracle's order: b_ih + b_hh, then the input terms,
+// then the recurrent terms, one fused multiply-add each (oracle/textgan_oracle.c lstm_cell_vec).
+__device__ __forceinline__ void leak_draw_row(const LeakArgs& a, int n, int i, int t, int b, float* lds, int64_t* fed_tok);
+__device__ __forceinline__ void leak_cell_row(const LeakArgs& a, int n, int64_t tk, float* cell);
+
+template <bool CELL>
 __global__ __launch_bounds__(256) void k_leak_draw(LeakArgs a) {
-    const int n = blockIdx.x, tid = threadIdx.x;
-    const int V = a.w.V, L = a.L, pos = a.pos;
+    extern __shared__ float lds[];
+    __shared__ int64_t fed_tok;
+    const int n = blockIdx.x;
     int i, t, b;
     row_ids(a, n, i, t, b);
-    const size_t orow = (((size_t)i * a.T + t) * a.B + b) * L;
-    if (pos < a.given[t]) {
+    leak_draw_row(a, n, i, t, b, lds, &fed_tok);
+    if constexpr (CELL) {
+        if (a.pos == a.L - 1) return;   // the reference's forward after the last token is never read
+        __syncthreads();
+        leak_cell_row(a, n, fed_tok, lds);
+    }
+}
+
+__device__ __forceinline__ void leak_cell_row(const LeakArgs& a, int n, int64_t tk, float* cell) {
+    const int H = a.w.H, K = a.w.K, E = a.w.E, tid = threadIdx.x;
+    float* xs = cell;          // [E] embedding of the token fed
+    float* hs = xs + E;        // [H] h before, then after
+    float* gs = hs + H;        // [4H] gate pre-activations
+    float* rs = gs + 4 * H;    // [K] the real goal in force
+    tk = tk < 0 ? 0 : (tk >= a.w.V ? a.w.V - 1 : tk);
+    for (int e = tid; e < E; e += 256) xs[e] = a.w.emb[(size_t)tk * E + e];
+    for (int h = tid; h < H; h += 256) hs[h] = a.hw[(size_t)n * H + h];
+    for (int k = tid; k < K; k += 256) rs[k] = a.rg_rd[(size_t)n * K + k];
+    __syncthreads();
+    for (int r = tid; r < 4 * H; r += 256) {
+        float acc = a.w.w_bih[r] + a.w.w_bhh[r];
+        const float* wi = a.w.w_wih + (size_t)r * E;
+        const float* wh = a.w.w_whh + (size_t)r * H;
+        for (int k = 0; k < E; ++k) acc = __builtin_fmaf(wi[k], xs[k], acc);
+        for (int k = 0; k < H; ++k) acc = __builtin_fmaf(wh[k], hs[k], acc);
+        gs[r] = acc;
+    }
+    __syncthreads();
+    for (int j = tid; j < H; j += 256) {
+        const float ig = tg_sigmoid(gs[j]);
+        const float fg = tg_sigmoid(gs[H + j]);
+        const float gg = tg_tanh(gs[2 * H + j]);
+        const float og = tg_sigmoid(gs[3 * H + j]);
+        const float cn = fg * a.cw[(size_t)n * H + j] + ig * gg;
+        const float hn = og * tg_tanh(cn);
+        a.cw[(size_t)n * H + j] = cn;
+        a.hw[(size_t)n * H + j] = hn;
+        hs[j] = hn;
+    }
+    __syncthreads();
+    // z = temperature * [rg (x) h_w | rg] (k_leak_worker's expression)
+    const float temp = a.pos > 1 ? 1.0f : a.w.temperature;
+    const int ldz = K * H + K;
+    float* z = a.z + (size_t)n * ldz;
+    for (int q = tid; q < ldz; q += 256) {
+        const bool tail = q >= K * H;
+        const int kq = tail ? q - K * H : q / H, hq = tail ? 0 : q % H;
+        const float rgk = rs[kq];
+        z[q] = tail ? temp * rgk : temp * rgk * hs[hq];
+    }
+}
+
+__device__ __forceinline__ void leak_draw_row(const LeakArgs& a, int n, int i, int t, int b, float* lds, int64_t* fed_tok) {
+    const int tid = threadIdx.x;
+    const int V = a.w.V, L = a.L, pos = a.pos;
+    if (t < 0) {
         if (tid == 0) {
             const int64_t tk = a.sentences[(size_t)b * L + pos];
-            a.out[orow + pos] = tk;
             a.fed[(size_t)n * L + pos] = tk;
             a.tok[n] = tk;
+            *fed_tok = tk;
         }
         return;
     }
-    extern __shared__ float lds[];
+    const size_t orow = (((size_t)i * a.T + t) * a.B + b) * L;
     const int Ls = a.Ls, GK = a.GK, NG = a.NG, NT = Ls / 16;
     float* ts = lds;                      // [8*NT] tile sums
     float* gs = ts + kNSpan * NT;         // [8*NG] group sums
     double* ss = reinterpret_cast<double*>(gs + kNSpan * NG + ((kNSpan * (NT + NG)) & 1));  // [8] span sums
     float* red = reinterpret_cast<float*>(ss + kNSpan);                                    // [256]
-    const float* lg = a.logits + (size_t)n * V;
+    // the row's own outputs of the position before -- its leader's when it joins here
+    const float* lg = a.logits + (size_t)(pos == a.given[t] ? b : n) * V;
     float m = TG_NEG_INF;
     for (int v = tid; v < V; v += 256) m = __builtin_fmaxf(m, lg[v]);
     red[tid] = m;
@@ -219,6 +358,7 @@ __global__ __launch_bounds__(256) void k_leak_draw(LeakArgs a) {
     const int64_t fedtok = a.forced ? a.forced[orow + pos] : (int64_t)tk;   // replay mode feeds the given token on
     a.fed[(size_t)n * L + pos] = fedtok;
     a.tok[n] = fedtok;
+    *fed_tok = fedtok;
 }
 
 // acc += A[i][:] . B[j][:] over K (A, B row-major with the contraction index contiguous): lane l feeds
@@ -360,14 +500,13 @@ __device__ void lstm_update(const float* g, const float* __restrict__ b_ih, cons
     }
 }
 
-// ---- worker cell, projection operand, manager cell, goal bookkeeping for 32 rows (LeakGAN_G.py:69-84)
-__global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
+// ---- worker cell and projection operand for 32 rows (LeakGAN_G.py:69-71, 80-95).  Needs the token of the position and
+// the real goal in force; nothing of this position's feature.
+__global__ __launch_bounds__(kLThreads) void k_leak_worker(LeakArgs a) {
     extern __shared__ float lds[];
-    const int H = a.w.H, K = a.w.K, E = a.w.E, G = a.w.G, N = a.N;
+    const int H = a.w.H, K = a.w.K, E = a.w.E, N = a.N;
     float* g = lds;                     // [4H][33]
     float* hl = g + 4 * H * 33;         // [32][H+1]
-    double* dred = reinterpret_cast<double*>(hl + 32 * (H + 1) + ((32 * (H + 1)) & 1));  // [32][8] partial norms
-    double* pk = dred + 32 * 8;         // [32][K] goal2goal(cur_goal) of this position
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int n0 = blockIdx.x * kLRows;
     const int j = lane & 31;
@@ -389,7 +528,7 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
     // thread = column q of the operand (its goal index and hidden unit fixed once), loop over the 32 rows: no
     // division inside the loop, the stores of a wave are 256 contiguous bytes of one row
     const int rows = tg_min(32, N - n0);
-    for (int idx = tid; idx < rows * K; idx += kLThreads) g[idx] = a.rg[(size_t)n0 * K + idx];   // g is free here (<= 32 x 64)
+    for (int idx = tid; idx < rows * K; idx += kLThreads) g[idx] = a.rg_rd[(size_t)n0 * K + idx];   // g is free here (<= 32 x 64)
     __syncthreads();
     for (int q = tid; q < ldz; q += kLThreads) {
         const bool tail = q >= K * H;
@@ -399,7 +538,27 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
             a.z[(size_t)(n0 + r) * ldz + q] = tail ? temp * rgk : temp * rgk * hl[r * (H + 1) + hq];
         }
     }
-    __syncthreads();
+    if (a.stamps && tid == 0) {
+        const long long c2 = tg_clock();
+        long long* o = a.stamps + (size_t)blockIdx.x * 8;
+        o[0] += c1 - c0; o[1] += c2 - c1; o[4] += 1;
+    }
+}
+
+// ---- manager cell and goal bookkeeping for 32 rows (LeakGAN_G.py:73-78; utils/rollout.py:89-93, 117-121).  Needs the
+// feature of the tokens up to this position (k_leak_mgates' product); feeds the worker only through the real goal, at
+// the positions where that is rebuilt.
+__global__ __launch_bounds__(kLThreads) void k_leak_manager(LeakArgs a) {
+    extern __shared__ float lds[];
+    const int H = a.w.H, K = a.w.K, G = a.w.G, N = a.N;
+    float* g = lds;                     // [4H][33]
+    float* hl = g + 4 * H * 33;         // [32][H+1]
+    double* dred = reinterpret_cast<double*>(hl + 32 * (H + 1) + ((32 * (H + 1)) & 1));  // [32][8] partial norms
+    double* pk = dred + 32 * 8;         // [32][K] goal2goal(cur_goal) of this position
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int n0 = blockIdx.x * kLRows;
+    const int j = lane & 31;
+    const int nj = tg_min(n0 + j, N - 1);
 
     const long long c2 = a.stamps ? tg_clock() : 0;
     // manager LSTM on the feature of the tokens so far
@@ -438,7 +597,7 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
         double nrm = sqrt(n2 > 0.0 ? n2 : 0.0);
         nrm = nrm < 1e-12 ? 1e-12 : nrm;
         const int pos = a.pos, step = a.w.step_size;
-        double* slot = a.ring + ((size_t)(pos & 3) * N + n) * K;
+        double* slot = a.ring + ((size_t)(pos & 3) * a.Nmax + n) * K;
         for (int k = 0; k < K; ++k) slot[k] = pk[r * K + k] / nrm;
         // goal_array[pos] = cur_goal; if pos > 0 and pos % step_size == 0: real_goal = sum(goal_array[pos-3 .. pos])
         // (an EMPTY slice when pos < 3), + goal_init[b] when pos == step_size (utils/rollout.py:89-93, 117-121)
@@ -450,39 +609,32 @@ __global__ __launch_bounds__(kLThreads) void k_leak_cells(LeakArgs a) {
             for (int k = 0; k < K; ++k) {
                 double v = 0.0;
                 if (pos >= 3)
-                    for (int jj = pos - 3; jj <= pos; ++jj) v += a.ring[((size_t)(jj & 3) * N + n) * K + k];
+                    for (int jj = pos - 3; jj <= pos; ++jj) v += a.ring[((size_t)(jj & 3) * a.Nmax + n) * K + k];
                 if (pos == step) v += gp[k];
                 pk[r * K + k] = v;
                 ss += v * v;
             }
             double rn = sqrt(ss);
             rn = rn < 1e-12 ? 1e-12 : rn;
-            for (int k = 0; k < K; ++k) a.rg[(size_t)n * K + k] = (float)(pk[r * K + k] / rn);
+            for (int k = 0; k < K; ++k) a.rg_wr[(size_t)n * K + k] = (float)(pk[r * K + k] / rn);
         }
     }
     if (a.stamps && tid == 0) {
         const long long c4 = tg_clock();
         long long* o = a.stamps + (size_t)blockIdx.x * 8;
-        o[0] += c1 - c0; o[1] += c2 - c1; o[2] += c3 - c2; o[3] += c4 - c3; o[4] += 1;
+        o[2] += c3 - c2; o[3] += c4 - c3;
     }
 }
 
 // ---- outputs[n, v] = z[n, :] . [work2goal.weight rows v*K .. v*K+K-1 | work2goal.bias[v*K ..]]
 // (work2goal(h_w).view(V, K) @ rg, LeakGAN_G.py:80-84, times the temperature folded into z).  Workgroup tile 128
 // vocabulary entries x 128 rows, 2 x 2 waves of 64 x 64 on v_mfma_f32_32x32x2_f32; both operands read from L2 with
-// 16-byte loads.  Row tiles none of whose rows draws its next token are skipped.
+// 16-byte loads.  (Every row that takes part draws its next token from these, or lends them to the rows that join.)
 __global__ __launch_bounds__(256) void k_leak_proj(LeakArgs a) {
     const int V = a.w.V, K = a.w.K, H = a.w.H, N = a.N;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int v0 = blockIdx.x * 128 + (wave & 1) * 64;
     const int r0 = blockIdx.y * 128 + (wave >> 1) * 64;
-    // any row of the workgroup's 128 whose next position is sampled?
-    int need = 0;
-    if (tid < 128) {
-        const int n = blockIdx.y * 128 + tid;
-        if (n < N) need = a.pos + 1 >= a.given[(n / a.B) % a.T];
-    }
-    if (!__syncthreads_or(need)) return;
     const int i = lane & 31, kk = lane >> 5;
     const int KH = K * H, ldz = KH + K;
     const float* arow[2];
@@ -573,10 +725,11 @@ struct LeakLayout {
 
 int span_len(int V) { return 16 * ((V + kNSpan * 16 - 1) / (kNSpan * 16)); }
 
-// rows per chunk: whole rollout indices (T*B rows each), logits of a chunk at most ~1 GiB
+// rows per chunk: the B leaders and whole rollout indices (T*B rows each), logits of a chunk at most ~1 GiB
 int chunk_indices(const TgLeakWeights* g, int B, int T, int n_i) {
-    const size_t per_i = (size_t)T * B;
-    size_t fit = ((size_t)1 << 30) / (per_i * g->V * sizeof(float));
+    const size_t per_i = (size_t)T * B, row = g->V * sizeof(float);
+    const size_t room = ((size_t)1 << 30) / row;
+    size_t fit = room > (size_t)B ? (room - B) / per_i : 0;
     if (fit < 1) fit = 1;
     return (int)(fit < (size_t)n_i ? fit : (size_t)n_i);
 }
@@ -584,25 +737,25 @@ int chunk_indices(const TgLeakWeights* g, int B, int T, int n_i) {
 LeakLayout layout(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, int T, int n_i) {
     LeakLayout o = {};
     const int ci = chunk_indices(g, B, T, n_i);
-    const size_t N = (size_t)ci * T * B;
+    const size_t N = (size_t)B + (size_t)ci * T * B;
     const int H = g->H, K = g->K;
     size_t off = 0;
     auto take = [&](size_t bytes) { const size_t at = off; off += al256(bytes); return at; };
     o.rows = (int)N;
     o.fed = take(N * L * sizeof(int64_t));
     o.tok = take(N * sizeof(int64_t));
-    o.feat = take(N * g->G * sizeof(float));
+    o.feat = take(2 * N * g->G * sizeof(float));   // even / odd positions
     o.hw = take(N * H * sizeof(float));
     o.cw = take(N * H * sizeof(float));
     o.hm = take(N * H * sizeof(float));
     o.cm = take(N * H * sizeof(float));
-    o.rg = take(N * K * sizeof(float));
+    o.rg = take(2 * N * K * sizeof(float));   // the goal in force and the one being rebuilt
     o.ring = take(4 * N * K * sizeof(double));
     o.z = take(N * ((size_t)K * H + K) * sizeof(float));
     o.mpre = take(N * (size_t)4 * H * sizeof(float));
     o.logits = take(N * (size_t)g->V * sizeof(float));
     o.prep = take(((size_t)K * H + K + (size_t)H * H + H + 1 + (size_t)B * K) * sizeof(double));
-    o.dis = take(tg_dis_workspace_bytes(d, (int)N, L));
+    o.dis = take(2 * al256(tg_dis_workspace_bytes(d, (int)N, L)));   // even / odd positions
     o.total = off;
     return o;
 }
@@ -688,13 +841,17 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     a.cw = reinterpret_cast<float*>(ws + lo.cw);
     a.hm = reinterpret_cast<float*>(ws + lo.hm);
     a.cm = reinterpret_cast<float*>(ws + lo.cm);
-    a.rg = reinterpret_cast<float*>(ws + lo.rg);
     a.ring = reinterpret_cast<double*>(ws + lo.ring);
     a.z = reinterpret_cast<float*>(ws + lo.z);
     a.mpre = reinterpret_cast<float*>(ws + lo.mpre);
     a.logits = reinterpret_cast<float*>(ws + lo.logits);
     a.prep = reinterpret_cast<const double*>(ws + lo.prep);
     for (int t = 0; t < T; ++t) a.given[t] = given_nums[t];
+    for (int t = 0; t < T; ++t) {      // insertion sort of the indices by given_num (stable)
+        int r = t;
+        while (r > 0 && given_nums[a.order[r - 1]] > given_nums[t]) { a.order[r] = a.order[r - 1]; --r; }
+        a.order[r] = t;
+    }
     a.B = B;
     a.L = L;
     a.T = T;
@@ -709,44 +866,185 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
 
     const size_t sm_draw = sizeof(float) * ((size_t)kNSpan * NT + (size_t)kNSpan * a.NG + 2) +
                            sizeof(double) * kNSpan + sizeof(float) * 256;
-    const size_t sm_cells = sizeof(float) * ((size_t)4 * H * 33 + (size_t)32 * (H + 1) + 2) +
-                            sizeof(double) * ((size_t)32 * 8 + (size_t)32 * K);
-    static TgLdsAttr attr_draw, attr_cells;
-    if ((rc = tg_lds_attr(attr_draw, reinterpret_cast<const void*>(&k_leak_draw), sm_draw, "k_leak_draw"))) return rc;
-    if ((rc = tg_lds_attr(attr_cells, reinterpret_cast<const void*>(&k_leak_cells), sm_cells, "k_leak_cells"))) return rc;
-    if (sm_draw > 160 * 1024 || sm_cells > 160 * 1024) {
-        tg_set_error("tg_leak_rollout: LDS need %zu / %zu bytes exceeds 160 KiB", sm_draw, sm_cells);
+    const size_t sm_worker = sizeof(float) * ((size_t)4 * H * 33 + (size_t)32 * (H + 1) + 2);
+    const size_t sm_manager = sm_worker + sizeof(double) * ((size_t)32 * 8 + (size_t)32 * K);
+    // the worker's cell rides in the draw kernel (one workgroup per row, vector units) while its weights are small
+    // enough to be re-read by every row from L2; wider cells keep k_leak_worker (32 rows per workgroup on the MFMA)
+    const char* sc = getenv("TG_LEAK_SPLIT_CELL");        // diagnostic: always k_leak_worker
+    const bool fused_cell = sizeof(float) * 4 * H * (size_t)(g->E + H) <= 64 * 1024 && !(sc && sc[0] == '1');
+    const size_t sm_cell = sizeof(float) * ((size_t)g->E + 5 * (size_t)H + K);
+    const size_t sm_step = sm_draw > sm_cell ? sm_draw : sm_cell;
+    static TgLdsAttr attr_draw, attr_step, attr_worker, attr_manager;
+    if ((rc = tg_lds_attr(attr_draw, reinterpret_cast<const void*>(&k_leak_draw<false>), sm_draw, "k_leak_draw"))) return rc;
+    if ((rc = tg_lds_attr(attr_step, reinterpret_cast<const void*>(&k_leak_draw<true>), sm_step, "k_leak_draw"))) return rc;
+    if ((rc = tg_lds_attr(attr_worker, reinterpret_cast<const void*>(&k_leak_worker), sm_worker, "k_leak_worker"))) return rc;
+    if ((rc = tg_lds_attr(attr_manager, reinterpret_cast<const void*>(&k_leak_manager), sm_manager, "k_leak_manager"))) return rc;
+    if (sm_draw > 160 * 1024 || sm_manager > 160 * 1024) {
+        tg_set_error("tg_leak_rollout: LDS need %zu / %zu bytes exceeds 160 KiB", sm_draw, sm_manager);
         return TG_ERR_ARG;
     }
+
+    // Streams (file header, "Streams"): the caller's carries the tokens' chain; three of the device's own carry the
+    // feature passes of even and of odd positions and the manager's cells.  Those streams and the events between them
+    // belong to the device, so calls on one device take turns here (the lock covers the enqueueing only).
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        tg_set_error("tg_leak_rollout: hipGetDevice failed or device index %d >= %d", dev, kMaxDevices);
+        return TG_ERR_LAUNCH;
+    }
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    LeakSide& sd = g_side[dev];
+    const char* one = getenv("TG_LEAK_ONE_STREAM");       // diagnostic: everything on the caller's stream
+    const bool side = !(one && one[0] == '1');
+    if (side && !sd.stream[2]) {
+        // the feature passes fill the units the tokens' chain leaves idle: lowest priority for their two streams
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
+        const char* np = getenv("TG_LEAK_NO_PRIO");
+        if (np && np[0] == '1') least = 0;
+        for (int q = 0; q < 3; ++q)
+            if (!sd.stream[q] &&
+                hipStreamCreateWithPriority(&sd.stream[q], hipStreamNonBlocking, q < 2 ? least : 0) != hipSuccess) {
+                tg_set_error("tg_leak_rollout: cannot create a side stream");
+                return TG_ERR_LAUNCH;
+            }
+    }
+    hipStream_t fstream[2] = {side ? sd.stream[0] : stream, side ? sd.stream[1] : stream};
+    hipStream_t mstream = side ? sd.stream[2] : stream;
+    bool ev_fail = false;
+    auto event = [&](size_t k) -> hipEvent_t {
+        while (sd.ev.size() <= k) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { ev_fail = true; return nullptr; }
+            sd.ev.push_back(e);
+        }
+        return sd.ev[k];
+    };
+    // record(k, s): event k = everything s has been given so far; wait(s, k): what s is given next starts after it
+    auto record = [&](size_t k, hipStream_t s) {
+        hipEvent_t e = side ? event(k) : nullptr;
+        if (side && (!e || hipEventRecord(e, s) != hipSuccess)) ev_fail = true;
+    };
+    auto wait = [&](hipStream_t s, size_t k) {
+        hipEvent_t e = side ? event(k) : nullptr;
+        if (side && (!e || hipStreamWaitEvent(s, e, 0) != hipSuccess)) ev_fail = true;
+    };
+    const size_t ev_draw = 0, ev_feat = (size_t)L, ev_mgr = 2 * (size_t)L;   // one event per position each
 
     const int n_prep = K * H + K + H * H + H + 1 + B * K;
     hipLaunchKernelGGL(k_leak_prep, dim3(n_prep), dim3(64), 0, stream, *g, B,
                        reinterpret_cast<double*>(ws + lo.prep));
     const int ci = chunk_indices(g, B, T, i_hi - i_lo);
-    int prepared_n = -1;     // row count the scorer's prepared weights in ws + lo.dis were laid out for
+    // the manager's output reaches the tokens only through the real goal, rebuilt at pos > 0 with pos % step_size == 0
+    // and read by the worker from pos + 1 on; the last worker pass is at L - 2, so the manager's chain ends at the
+    // last such pos <= L - 3 (none: it never runs)
+    int last_update = -1;
+    for (int p = 1; p <= L - 3; ++p)
+        if (p % g->step_size == 0) last_update = p;
+    const size_t dis_bytes = tg_dis_workspace_bytes(d, lo.rows, L);
+    int prepared_n[2] = {-1, -1};   // row count the scorer's prepared weights in each of the two workspaces were laid out for
     for (int i0 = i_lo; i0 < i_hi; i0 += ci) {
         const int ni = (i_hi - i0 < ci) ? i_hi - i0 : ci;
         a.i0 = i0;
-        a.N = ni * T * B;
-        hipLaunchKernelGGL(k_leak_init, dim3(a.N), dim3(256), 0, stream, a);
-        for (int pos = 0; pos < L; ++pos) {
+        a.ni = ni;
+        a.Nmax = B + ni * T * B;
+        a.N = a.Nmax;
+        float* rgbuf[2] = {reinterpret_cast<float*>(ws + lo.rg), reinterpret_cast<float*>(ws + lo.rg) + (size_t)a.Nmax * K};
+        float* featbuf[2] = {reinterpret_cast<float*>(ws + lo.feat),
+                             reinterpret_cast<float*>(ws + lo.feat) + (size_t)a.Nmax * g->G};
+        a.rg_rd = rgbuf[0];
+        a.rg_wr = rgbuf[0];
+        a.feat = featbuf[0];
+        hipLaunchKernelGGL(k_leak_init, dim3(a.Nmax), dim3(256), 0, stream, a);
+        // rows taking part at a position: the leaders and the rows whose given_num it has reached (row_ids)
+        auto n_live = [&](int pos) {
+            int groups = 0;
+            for (int t = 0; t < T; ++t) groups += given_nums[t] <= pos;
+            return B + groups * ni * B;
+        };
+        const int step = g->step_size;
+        // real goals rebuilt before position pos: the one in force there is rgbuf[epoch & 1]
+        auto epoch_at = [&](int pos) { const int hi = pos - 1 < last_update ? pos - 1 : last_update; return hi >= 1 ? hi / step : 0; };
+        auto rebuilds = [&](int pos) { return pos > 0 && pos <= last_update && pos % step == 0; };
+        auto at = [&](int pos) {
             a.pos = pos;
+            a.N = n_live(pos);
+            a.rg_rd = rgbuf[epoch_at(pos) & 1];
+            a.rg_wr = rgbuf[(epoch_at(pos) + 1) & 1];
+            a.feat = featbuf[pos & 1];
+        };
+        auto tokens_pass = [&](int pos) {
+            at(pos);
+            // the worker -- and the rows that join here -- read the goal the manager pass of the position before rebuilt
+            if (rebuilds(pos - 1)) wait(stream, ev_mgr + pos - 1);
+            const int joined = pos > 0 ? n_live(pos - 1) : B;
+            if (a.N > joined) {
+                LeakArgs f = a;
+                f.rg_wr = const_cast<float*>(a.rg_rd);
+                hipLaunchKernelGGL(k_leak_fork, dim3(a.N - joined), dim3(256), 0, stream, f, joined, 0);
+            }
             tg_prof_begin(TG_KERNEL_LEAK_DRAW, stream);
-            hipLaunchKernelGGL(k_leak_draw, dim3(a.N), dim3(256), sm_draw, stream, a);
+            if (fused_cell)
+                hipLaunchKernelGGL(k_leak_draw<true>, dim3(a.N), dim3(256), sm_step, stream, a);
+            else
+                hipLaunchKernelGGL(k_leak_draw<false>, dim3(a.N), dim3(256), sm_draw, stream, a);
             tg_prof_end(stream);
-            if (pos == L - 1) break;   // the reference's forward after the last token is never read
-            rc = tg_dis_features(d, a.fed, a.N, L, a.feat, ws + lo.dis, tg_dis_workspace_bytes(d, a.N, L),
-                                 prepared_n == a.N, stream);
-            if (rc) return rc;
-            prepared_n = a.N;
-            tg_prof_begin(TG_KERNEL_LEAK_CELLS, stream);
-            hipLaunchKernelGGL(k_leak_mgates, dim3((a.N + 31) / 32, (4 * g->H) / 32), dim3(256), 0, stream, a);
-            hipLaunchKernelGGL(k_leak_cells, dim3((a.N + kLRows - 1) / kLRows), dim3(kLThreads), sm_cells, stream, a);
-            tg_prof_end(stream);
+            if (pos == L - 1) return;   // the reference's forward after the last token is never read
+            if (pos <= last_update) record(ev_draw + pos, stream);
+            if (!fused_cell) {
+                tg_prof_begin(TG_KERNEL_LEAK_CELLS, stream);
+                hipLaunchKernelGGL(k_leak_worker, dim3((a.N + kLRows - 1) / kLRows), dim3(kLThreads), sm_worker, stream, a);
+                tg_prof_end(stream);
+            }
             tg_prof_begin(TG_KERNEL_LEAK_PROJ, stream);
             hipLaunchKernelGGL(k_leak_proj, dim3((g->V + 127) / 128, (a.N + 127) / 128), dim3(256), 0, stream, a);
             tg_prof_end(stream);
+        };
+        auto manager_pass = [&](int pos) -> int {
+            at(pos);
+            // the feature of the tokens up to pos: needs this position's draw; its output buffer and workspace were
+            // last used by position pos - 2, whose manager pass must be through with them.  Tokens behind pos are read
+            // as padding whatever the draws running ahead have written there by now.
+            hipStream_t fs = fstream[pos & 1];
+            wait(fs, ev_draw + pos);
+            if (pos >= 2) wait(fs, ev_mgr + pos - 2);
+            const int rc2 = tg_dis_features(d, a.fed, a.N, a.Nmax, L, pos + 1, a.feat,
+                                            ws + lo.dis + (pos & 1) * al256(dis_bytes), dis_bytes,
+                                            prepared_n[pos & 1] == a.Nmax, fs);
+            if (rc2) return rc2;
+            prepared_n[pos & 1] = a.Nmax;
+            record(ev_feat + pos, fs);
+            wait(mstream, ev_feat + pos);
+            const int joined = pos > 0 ? n_live(pos - 1) : B;
+            if (a.N > joined) hipLaunchKernelGGL(k_leak_fork, dim3(a.N - joined), dim3(256), 0, mstream, a, joined, 1);
+            tg_prof_begin(TG_KERNEL_LEAK_CELLS, mstream);
+            hipLaunchKernelGGL(k_leak_mgates, dim3((a.N + 31) / 32, (4 * g->H) / 32), dim3(256), 0, mstream, a);
+            hipLaunchKernelGGL(k_leak_manager, dim3((a.N + kLRows - 1) / kLRows), dim3(kLThreads), sm_manager, mstream, a);
+            tg_prof_end(mstream);
+            record(ev_mgr + pos, mstream);
+            return TG_OK;
+        };
+        // Enqueued in segments that end where a goal is rebuilt (the tokens' chain needs nothing from the side streams
+        // inside one): the segment's token passes first, so that the caller's stream never waits for the host to get
+        // through the side streams' launches, then its manager passes; the next segment's first worker waits for the
+        // last of them.
+        for (int pos = 0; pos < L;) {
+            int seg_end = L - 1;
+            for (int p = pos; p <= last_update; ++p)
+                if (rebuilds(p)) { seg_end = p; break; }
+            for (int p = pos; p <= seg_end; ++p) tokens_pass(p);
+            for (int p = pos; p <= seg_end && p <= last_update; ++p)
+                if ((rc = manager_pass(p))) return rc;
+            pos = seg_end + 1;
         }
+        // whatever follows on the caller's stream (the next chunk's reset, the caller's own work, freeing the
+        // workspace) comes after the side streams' last work: the manager pass at last_update, behind every feature pass
+        if (last_update >= 0) wait(stream, ev_mgr + last_update);
+    }
+    if (ev_fail) {
+        (void)hipGetLastError();
+        tg_set_error("tg_leak_rollout: event record / wait between the streams failed");
+        return TG_ERR_LAUNCH;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
