@@ -932,6 +932,45 @@ def test_leak_reward_c1_shape_full_vs_oracle():
         assert torch.equal(comp[:, t, :, :given[t]], _t(sent)[:, :given[t]].expand(R, B, given[t]))
 
 
+@pytest.mark.parametrize("H", [32, 64])
+def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, monkeypatch):
+    """tg_leak_rollout shares the sentence-fed part of every row with one leader row per sentence, orders its rows by
+    given_num and spreads the call over four streams.  None of that may show in the tokens: a call with given_nums
+    unsorted, repeated and equal to L gives, for each of them, exactly the rows the plain ascending call gives for that
+    given_num under the same uniforms (the sentence itself for given_num = L); and the call with everything on one
+    stream (TG_LEAK_ONE_STREAM=1) gives the same bits.  H = 32 takes the worker cell inside the draw kernel, H = 64 the
+    kernel of its own; TG_LEAK_SPLIT_CELL=1 forces the latter (different summation order: rows agree up to CDF ties)."""
+    V, E, K, L, B, R, step = 300, 32, 16, 20, 7, 3, 4
+    gsd = synth.leak_state(V, E, H, K, 1720, B, seed=5, std=0.2)
+    dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=5)
+    gen = tg.modules.load_numpy_state(tg.modules.LeakGAN_G(E, H, V, L, goal_size=K, step_size=step, batch_size=B), gsd, DEV)
+    dis = tg.modules.load_numpy_state(tg.modules.SeqGAN_D(64, V, dropout=0.2), dsd, DEV).eval()
+    T = L // step
+    given = [t * step + 1 for t in range(T)]
+    sent, u = synth.tokens(91, (B, L), V), synth.uniform01(92, (R, T, L, B))
+    std = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u))
+    mixed = [9, 1, L, 9, 17, 5, 13]
+    um = np.stack([u[:, given.index(g)] if g in given else u[:, 0] for g in mixed], axis=1)
+    got = tg.ops.leak_rollout(gen, dis, _t(sent), R, mixed, _t(np.ascontiguousarray(um)))
+    for j, g in enumerate(mixed):
+        if g == L:
+            assert torch.equal(got[:, j], _t(sent).expand(R, B, L))
+        else:
+            assert torch.equal(got[:, j], std[:, given.index(g)]), "given_num %d at index %d" % (g, j)
+    # a shard of the rollout index: its own leaders, the same rows
+    part = torch.full_like(std, -1)
+    tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), i_lo=2, i_hi=3, out=part)
+    assert torch.equal(part[2], std[2]) and bool((part[:2] == -1).all())
+    monkeypatch.setenv("TG_LEAK_ONE_STREAM", "1")
+    assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u)), std)
+    monkeypatch.delenv("TG_LEAK_ONE_STREAM")
+    monkeypatch.setenv("TG_LEAK_SPLIT_CELL", "1")
+    other = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u))
+    assert (other == std).all(-1).float().mean() >= 0.97
+    if H > 32:
+        assert torch.equal(other, std)   # the switch changes nothing where the cell has its own kernel anyway
+
+
 @pytest.mark.parametrize("V,E,H,K,L,B,R,step", [(3, 32, 32, 16, 20, 1, 1, 4), (40, 32, 64, 8, 20, 3, 2, 5),
                                                 (150, 64, 128, 16, 24, 33, 1, 3), (9, 32, 32, 1, 20, 2, 3, 10),
                                                 (64, 48, 96, 5, 21, 5, 2, 7), (40009, 32, 32, 4, 20, 2, 1, 10)])

@@ -526,15 +526,15 @@ __device__ __forceinline__ void block_atomic_max(unsigned m, unsigned* out) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_absmax(const float* x, size_t n, unsigned* out) {
+// workgroup bx of nb: |max| of x[0..n) as ordered bits (NaN sorts high: scale 1 below)
+__device__ __forceinline__ unsigned absmax_part(const float* x, size_t n, int bx, int nb) {
     unsigned m = 0;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);  // |x| as ordered bits (NaN sorts high: scale 1 below)
-    block_atomic_max(m, out);
+    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nb * 256)
+        m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    return m;
 }
 
-__global__ void k_make_scales(const unsigned* absmax, float* scales) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void make_scales_conv(const unsigned* absmax, float* scales) {
     float sc[2];
     for (int i = 0; i < 2; ++i) {
         const float m = __uint_as_float(absmax[i]);
@@ -571,14 +571,14 @@ struct SplitArgs {
 // mt, window row tau, piece p (0-3 hi / 4-7 lo of the k block p&3), lane: 8 halves
 // W[min(mt*32 + (lane&31), n_k-1)][tau*64 + 16*(p&3) + 8*(lane>>5) + 0..7] -- one 16-B store per thread, and every
 // load instruction of a wave reads 1 KiB contiguous.
-__global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
+__device__ void split_weights_part(const SplitArgs& a, int y, int bx, int nb) {
     const float sc = a.scales[0];
-    if ((int)blockIdx.y >= a.n_filters) {  // a merged tile: [tau < fmax][8 pieces][64 lanes], zero past a row's width
-        const int m = blockIdx.y - a.n_filters;
+    if (y >= a.n_filters) {  // a merged tile: [tau < fmax][8 pieces][64 lanes], zero past a row's width
+        const int m = y - a.n_filters;
         const MergedTile& mt = a.merged[m];
         const int total = mt.fmax * 8 * 64;
         f16x8* dst = reinterpret_cast<f16x8*>(a.w16 + a.mwoff[m]);
-        for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        for (int i = bx * 256 + threadIdx.x; i < total; i += nb * 256) {
             const int lane = i & 63, p = (i >> 6) & 7, tau = i >> 9;
             const int row = lane & 31;
             f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
             }
             dst[i] = o;
         }
-        if (blockIdx.x == 0 && threadIdx.x < 32) {
+        if (bx == 0 && threadIdx.x < 32) {
             const int row = threadIdx.x;
             MergedMeta& mm = a.mmeta[m];
             if (row < mt.nrow) {
@@ -612,11 +612,11 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
         }
         return;
     }
-    const int k = blockIdx.y;
+    const int k = y;
     const int f = a.f[k], nk = a.nk[k], K = f * kEd;
     const int total = ((a.nfull[k] + 31) / 32) * f * 8 * 64;
     f16x8* dst = reinterpret_cast<f16x8*>(a.w16 + a.woff[k]);
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    for (int i = bx * 256 + threadIdx.x; i < total; i += nb * 256) {
         const int lane = i & 63, p = (i >> 6) & 7, mtau = i >> 9;
         const int tau = mtau % f, mt = mtau / f;
         const int row = tg_min(mt * 32 + (lane & 31), nk - 1);
@@ -632,13 +632,6 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_absmax_banks(const SplitArgs a, unsigned* out) {
-    const int k = blockIdx.y, cnt = a.nk[k] * a.f[k] * kEd;
-    unsigned m = 0;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < cnt; i += gridDim.x * 256)
-        m = max(m, __float_as_uint(a.src[k][i]) & 0x7fffffffu);
-    block_atomic_max(m, out);
-}
 
 // Running max over time of the sentences' window values: cv[b][t][f] <- max_{t' <= t} cv[b][t'][f]
 // (entries with t >= L - f_k + 1 of a width are never read).
@@ -1104,11 +1097,11 @@ void k_dis_highway_frag(const Hw2Args a) {
 
 // W_hw -> A pieces: piece ((mb*KB + kb)*2 + part)*64 + lane = W_hw[32mb + lane%32][16kb + 8(lane/32) + 0..7] * sW as
 // 8 halves (hi or lo); rows / columns past F are zero.
-__global__ __launch_bounds__(256) void k_hw_make_frag(const float* __restrict__ hw_w, int F, int MB, int KB,
-                                                      const float* scales, f16x8* __restrict__ Wf) {
+__device__ void hw_make_frag_part(const float* __restrict__ hw_w, int F, int MB, int KB, const float* scales,
+                                  f16x8* __restrict__ Wf, int bx, int nb) {
     const float sW = scales[4];
     const long total = (long)MB * KB * 128;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)bx * 256 + threadIdx.x; i < total; i += (long)nb * 256) {
         const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
         const long q = i >> 7;
         const int kb = (int)(q % KB), mb = (int)(q / KB);
@@ -1130,11 +1123,11 @@ __global__ __launch_bounds__(256) void k_hw_make_frag(const float* __restrict__ 
 
 // pieces of the pooled fragments whose features lie past F (the k padding up to a multiple of 32): zero, so that the
 // GEMM meets 0 . 0 there and not whatever the workspace held
-__global__ __launch_bounds__(256) void k_pf_zero_pad(f16x8* __restrict__ Pf, int RB, int KB, int F) {
+__device__ void pf_zero_pad_part(f16x8* __restrict__ Pf, int RB, int KB, int F, int bx, int nb) {
     const int kb_first = F >> 4;   // first k block with a feature >= F (F % 8 == 0)
     const int nkb = KB - kb_first;
     const long total = (long)RB * nkb * 128;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    for (long i = (long)bx * 256 + threadIdx.x; i < total; i += (long)nb * 256) {
         const int lane = (int)(i & 63), part = (int)((i >> 6) & 1);
         const long q = i >> 7;
         const int kb = kb_first + (int)(q % nkb);
@@ -1143,20 +1136,12 @@ __global__ __launch_bounds__(256) void k_pf_zero_pad(f16x8* __restrict__ Pf, int
     }
 }
 
-// |max| of all conv biases -> out (one workgroup)
-__global__ __launch_bounds__(256) void k_absmax_bias(const TgDisWeights w, unsigned* out) {
-    unsigned m = 0;
-    for (int k = 0; k < w.n_filters; ++k)
-        for (int i = threadIdx.x; i < w.n[k]; i += 256) m = max(m, __float_as_uint(w.conv_b[k][i]) & 0x7fffffffu);
-    block_atomic_max(m, out);
-}
 
 // Scales of the fragment highway, all known before the conv runs: sW from |max| of W_hw (absmax[2]); sP from a BOUND
 // on the pooled features, |conv| <= 64 f_max max|w| max|e| + max|b| (absmax[0], [1], [3]) -- the conv epilogue splits
 // its outputs with it, so it cannot wait for their actual maximum.  fp16 is a floating format: an over-estimate by
 // 2^10 still leaves the (hi, lo) pair 22 significant bits for every feature within 2^-6 of the largest.
-__global__ void k_make_scales_hw(const unsigned* absmax, float* scales, int fmax) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__device__ void make_scales_hw(const unsigned* absmax, float* scales, int fmax) {
     auto pow2_for = [](float m) {
         int ex = 0;
         float sc = 1.f;
@@ -1173,6 +1158,57 @@ __global__ void k_make_scales_hw(const unsigned* absmax, float* scales, int fmax
     scales[5] = sP;
     scales[6] = 1.f / (sW * sP);
     scales[7] = 1.f / sP;
+}
+
+// ---- the split-fp16 preparation of a call in three launches (it is a dependent chain in front of the conv: ten
+// launches of a few microseconds each cost more in the gaps between them than in the kernels)
+struct PrepArgs {
+    SplitArgs s;
+    const float* emb;
+    size_t n_emb;
+    const float* hw_w;     // null: no fragment highway (its |max|, scales, pieces and padding are skipped)
+    size_t n_hw;
+    unsigned* absmax;      // [0] conv weights, [1] embedding table, [2] W_hw, [3] conv biases; zeroed by the host
+    float* scales;
+    int fmax, F, MB, KB, RB;
+    f16x8* Wf;
+    f16x8* Pf;
+};
+
+// blockIdx.y: conv bank k | n_filters: embedding table | n_filters + 1: conv biases | n_filters + 2: W_hw
+__global__ __launch_bounds__(256) void k_prep_absmax(const PrepArgs a) {
+    const int y = blockIdx.y, nf = a.s.n_filters, bx = blockIdx.x, nb = gridDim.x;
+    unsigned m = 0;
+    unsigned* out = a.absmax;
+    if (y < nf) {
+        m = absmax_part(a.s.src[y], (size_t)a.s.nk[y] * a.s.f[y] * kEd, bx, nb);
+    } else if (y == nf) {
+        m = absmax_part(a.emb, a.n_emb, bx, nb);
+        out += 1;
+    } else if (y == nf + 1) {
+        if (bx == 0)
+            for (int k = 0; k < nf; ++k)
+                for (int i = threadIdx.x; i < a.s.nk[k]; i += 256) m = max(m, __float_as_uint(a.s.bias[k][i]) & 0x7fffffffu);
+        out += 3;
+    } else {
+        m = absmax_part(a.hw_w, a.n_hw, bx, nb);
+        out += 2;
+    }
+    block_atomic_max(m, out);
+}
+
+__global__ void k_prep_scales(const PrepArgs a) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    make_scales_conv(a.absmax, a.scales);
+    if (a.hw_w) make_scales_hw(a.absmax, a.scales, a.fmax);
+}
+
+// blockIdx.y: conv bank / merged tile | then 4 slices of W_hw's pieces | then the pooled pieces' k padding
+__global__ __launch_bounds__(256) void k_prep_split(const PrepArgs a) {
+    const int y = blockIdx.y, nc = a.s.n_filters + a.s.n_merged, bx = blockIdx.x, nb = gridDim.x;
+    if (y < nc) split_weights_part(a.s, y, bx, nb);
+    else if (y < nc + 4) hw_make_frag_part(a.hw_w, a.F, a.MB, a.KB, a.scales, a.Wf, (y - nc) * nb + bx, 4 * nb);
+    else pf_zero_pad_part(a.Pf, a.RB, a.KB, a.F, bx, nb);
 }
 
 struct FinalArgs {
@@ -1420,19 +1456,12 @@ size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
 // of all conv banks, the two power-of-two scales, and the (hi, lo) halves of the conv weights.
 // reuse: the workspace still holds the scales and halves an earlier call wrote for the SAME weights and N (the
 // position loop of tg_leak_rollout): only the offsets are recomputed.
-int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, hipStream_t stream, bool reuse) {
-    unsigned* absmax = (unsigned*)scal;          // [0] conv weights, [1] embedding table, [2] W_hw, [3] conv biases
+void prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, SplitArgs& sa) {
     float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e), -} x 2 (conv, highway)
-    if (!reuse && hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
-        tg_set_error("hipMemsetAsync failed");
-        return TG_ERR_LAUNCH;
-    }
-    if (!reuse) tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
-    SplitArgs sa = {};
+    sa = SplitArgs{};
     const MergePlan pl = plan_merge(w);
-    int off = 0, maxcount = 0, maxelems = 0, foff = 0;
+    int off = 0, foff = 0;
     for (int k = 0; k < w->n_filters; ++k) {
-        const int cnt = w->n[k] * w->f[k] * kEd;
         sa.src[k] = w->conv_w[k];
         sa.bias[k] = w->conv_b[k];
         sa.woff[k] = off;
@@ -1442,10 +1471,7 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
         sa.foff[k] = foff;
         foff += w->n[k];
         ca.woff[k] = off;
-        const int pieces = (int)(conv_frag_halves(w, k) / 8);
-        off += pieces * 8;
-        maxcount = pieces > maxcount ? pieces : maxcount;
-        maxelems = cnt > maxelems ? cnt : maxelems;
+        off += (int)(conv_frag_halves(w, k) / 8) * 8;
     }
     sa.n_filters = w->n_filters;
     sa.n_merged = pl.n_merged;
@@ -1460,19 +1486,40 @@ int prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal
     ca.mmeta = sa.mmeta;
     sa.w16 = w16;
     sa.scales = scales;
-    if (!reuse) {
-        hipLaunchKernelGGL(k_absmax_banks, dim3(tg_min_host((maxelems + 255) / 256, 64), w->n_filters), dim3(256), 0,
-                           stream, sa, absmax);
-        const size_t ne = (size_t)w->V * kEd;
-        hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((ne + 255) / 256), 256)), dim3(256), 0, stream, w->emb, ne,
-                           absmax + 1);
-        hipLaunchKernelGGL(k_make_scales, dim3(1), dim3(64), 0, stream, absmax, scales);
-        hipLaunchKernelGGL(k_split_weights, dim3(tg_min_host((maxcount + 255) / 256, 256), w->n_filters + pl.n_merged),
-                           dim3(256), 0, stream, sa);
-        tg_prof_end(stream);
-    }
     ca.w16 = w16;
     ca.scales = scales;
+}
+
+// The launches of the preparation: |max| of every tensor, the scales, the (hi, lo) pieces.  hw16 null: the conv's only.
+int launch_prepare(const SplitArgs& sa, const TgDisWeights* w, void* scal, _Float16* hw16, void* pooled, int NL,
+                   hipStream_t stream) {
+    PrepArgs pa = {};
+    pa.s = sa;
+    pa.emb = w->emb;
+    pa.n_emb = (size_t)w->V * kEd;
+    pa.absmax = (unsigned*)scal;
+    pa.scales = (float*)((char*)scal + 16);
+    pa.fmax = 1;
+    for (int k = 0; k < w->n_filters; ++k) pa.fmax = w->f[k] > pa.fmax ? w->f[k] : pa.fmax;
+    if (hw16) {
+        pa.hw_w = w->hw_w;
+        pa.n_hw = (size_t)w->F * w->F;
+        pa.F = w->F;
+        pa.MB = hw_mb(w->F);
+        pa.KB = hw_kb(w->F);
+        pa.RB = (int)hw_rb(NL);
+        pa.Wf = reinterpret_cast<f16x8*>(hw16);
+        pa.Pf = reinterpret_cast<f16x8*>(pooled);
+    }
+    if (hipMemsetAsync(pa.absmax, 0, 16, stream) != hipSuccess) {
+        tg_set_error("hipMemsetAsync failed");
+        return TG_ERR_LAUNCH;
+    }
+    tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+    hipLaunchKernelGGL(k_prep_absmax, dim3(256, w->n_filters + (hw16 ? 3 : 2)), dim3(256), 0, stream, pa);
+    hipLaunchKernelGGL(k_prep_scales, dim3(1), dim3(64), 0, stream, pa);
+    hipLaunchKernelGGL(k_prep_split, dim3(256, w->n_filters + sa.n_merged + (hw16 ? 5 : 0)), dim3(256), 0, stream, pa);
+    tg_prof_end(stream);
     return TG_OK;
 }
 
@@ -1552,9 +1599,9 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     rc = prepare_conv(ca, w, sentences ? B : N, L, &sm, sentences ? 1 : 8, valid_len);
     if (rc) return rc;
     ca.valid_len = valid_len < 0 ? L : valid_len;
+    SplitArgs sa;
     if (w->precision == TG_DIS_SPLIT_F16) {
-        rc = prepare_split(ca, w, w16, scal, stream, reuse);
-        if (rc) return rc;
+        prepare_split(ca, w, w16, scal, sa);
     } else if (w->precision != TG_DIS_FP32) {
         tg_set_error("tg_dis_score: unknown precision %d", w->precision);
         return TG_ERR_ARG;
@@ -1566,24 +1613,11 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
                            reinterpret_cast<uintptr_t>(dropout_uniforms) | reinterpret_cast<uintptr_t>(feature_out);
     const bool frag = ca.w16 != nullptr && (w->F & 7) == 0 && (al16 & 15) == 0 && (size_t)N < ((size_t)1 << 31) - 256;
     const int KB = hw_kb(w->F), MBp = hw_mb(w->F);
+    if (ca.w16 && !reuse) {
+        rc = launch_prepare(sa, w, scal, frag ? hw16 : nullptr, pooled, NL, stream);
+        if (rc) return rc;
+    }
     if (frag) {
-        unsigned* absmax = (unsigned*)scal;
-        float* scales = (float*)((char*)scal + 16);
-        if (!reuse) {
-            int fmax = 1;
-            for (int k = 0; k < w->n_filters; ++k) fmax = w->f[k] > fmax ? w->f[k] : fmax;
-            const size_t nw = (size_t)w->F * w->F;
-            tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
-            hipLaunchKernelGGL(k_absmax, dim3(tg_min_host((int)((nw + 255) / 256), 512)), dim3(256), 0, stream, w->hw_w,
-                               nw, absmax + 2);
-            hipLaunchKernelGGL(k_absmax_bias, dim3(1), dim3(256), 0, stream, *w, absmax + 3);
-            hipLaunchKernelGGL(k_make_scales_hw, dim3(1), dim3(64), 0, stream, absmax, scales, fmax);
-            hipLaunchKernelGGL(k_hw_make_frag, dim3(1024), dim3(256), 0, stream, w->hw_w, w->F, MBp, KB, scales,
-                               reinterpret_cast<f16x8*>(hw16));
-            hipLaunchKernelGGL(k_pf_zero_pad, dim3(256), dim3(256), 0, stream, reinterpret_cast<f16x8*>(pooled),
-                               (int)hw_rb(NL), KB, w->F);
-            tg_prof_end(stream);
-        }
         ca.pfrag = reinterpret_cast<_Float16*>(pooled);
         ca.KBp = KB;
     }

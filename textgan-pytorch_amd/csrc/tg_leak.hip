@@ -896,19 +896,13 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     LeakSide& sd = g_side[dev];
     const char* one = getenv("TG_LEAK_ONE_STREAM");       // diagnostic: everything on the caller's stream
     const bool side = !(one && one[0] == '1');
-    if (side && !sd.stream[2]) {
-        // the feature passes fill the units the tokens' chain leaves idle: lowest priority for their two streams
-        int least = 0, greatest = 0;
-        if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) least = 0;
-        const char* np = getenv("TG_LEAK_NO_PRIO");
-        if (np && np[0] == '1') least = 0;
-        for (int q = 0; q < 3; ++q)
-            if (!sd.stream[q] &&
-                hipStreamCreateWithPriority(&sd.stream[q], hipStreamNonBlocking, q < 2 ? least : 0) != hipSuccess) {
-                tg_set_error("tg_leak_rollout: cannot create a side stream");
-                return TG_ERR_LAUNCH;
-            }
-    }
+    // (plain streams on purpose: with low-priority streams for the feature passes, two processes sharing one GPU
+    // stopped making progress -- the caller's stream waiting at a barrier for a queue the scheduler no longer mapped)
+    for (int q = 0; side && q < 3; ++q)
+        if (!sd.stream[q] && hipStreamCreateWithFlags(&sd.stream[q], hipStreamNonBlocking) != hipSuccess) {
+            tg_set_error("tg_leak_rollout: cannot create a side stream");
+            return TG_ERR_LAUNCH;
+        }
     hipStream_t fstream[2] = {side ? sd.stream[0] : stream, side ? sd.stream[1] : stream};
     hipStream_t mstream = side ? sd.stream[2] : stream;
     bool ev_fail = false;
