@@ -1444,12 +1444,23 @@ inline int hw_nchunk(const TgDisWeights* w) {                  // partial-logit 
     return a > b ? a : b;
 }
 
-size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
+// the part of a workspace that belongs to one call: pooled features (or their pieces), partial logits, prefix table
+size_t call_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
     return align256(pooled_bytes(w, N)) + align256(sizeof(float) * (size_t)N * hw_nchunk(w) * kMaxOut) +
-           align256(sizeof(float) * (size_t)B_prefix * L * w->F) +
-           align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256 +
-           align256(hw_weight_bytes(w)) +
-           align256(sizeof(float) * w->F) + align256(sizeof(int64_t) * L);   // tg_dis_features: padpool, L padding tokens
+           align256(sizeof(float) * (size_t)B_prefix * L * w->F);
+}
+// the part that holds the prepared weights: conv pieces, scales, highway pieces; for tg_dis_features also the pooled
+// features of an all-padding sequence and L padding tokens
+size_t weights_bytes(const TgDisWeights* w, int L) {
+    return align256(2 * sizeof(_Float16) * conv_weight_count(w)) + 256 + align256(hw_weight_bytes(w)) +
+           align256(sizeof(float) * w->F) + align256(sizeof(int64_t) * L);
+}
+size_t ws_bytes(const TgDisWeights* w, int N, int L, int B_prefix) {
+    return call_bytes(w, N, L, B_prefix) + weights_bytes(w, L);
+}
+
+__global__ __launch_bounds__(256) void k_pf_zero_pad(f16x8* Pf, int RB, int KB, int F) {
+    pf_zero_pad_part(Pf, RB, KB, F, blockIdx.x, gridDim.x);
 }
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
@@ -1556,13 +1567,25 @@ int launch_highway_frag(Hw2Args& a, int MBp, int N, hipStream_t stream) {
     return launch_highway_frag_t<2, 2, 2, 2>(a, MBp, N, stream);
 }
 
+// tg_dis_features' extras (all defaults: tg_dis_score)
+struct FeatOpts {
+    enum { kRun = 0, kPrepareOnly = 1, kPadOnly = 2 };
+    bool reuse = false;          // the prepared weights are in place (same w, same N_layout)
+    int valid_len = -1;          // >= 0: tokens at positions >= valid_len are padding (and the all-padding windows skipped)
+    int N_layout = -1;           // sequences the workspace is laid out for (>= N)
+    void* weights_ws = nullptr;  // the prepared weights live here (weights_bytes) and not behind the per-call part
+    int mode = kRun;             // kPrepareOnly: weights, padpool, this workspace's k padding; kPadOnly: the k padding
+};
+
 // sentences == nullptr: plain scoring of N arbitrary sequences.
 // sentences != nullptr: seqs is [R,L,B,L] rollout completions (N = R*L*B), prefix reuse.
 int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const int64_t* sentences, int B, int col,
                float dropout_p, const float* dropout_uniforms, float* reward_out, float* logits_out,
-               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream, bool reuse = false,
-               int valid_len = -1, int N_layout = -1) {
-    const int NL = N_layout < N ? N : N_layout;   // sequences the workspace is laid out for
+               float* feature_out, void* workspace, size_t workspace_bytes, hipStream_t stream,
+               const FeatOpts& fo = FeatOpts()) {
+    const bool reuse = fo.reuse;
+    const int valid_len = fo.valid_len;
+    const int NL = fo.N_layout < N ? N : fo.N_layout;   // sequences the workspace is laid out for
     if (N < 0 || L < 1 || (N > 0 && !seqs)) {   // an empty batch is a no-op
         tg_set_error("tg_dis_score: bad arguments (N=%d L=%d)", N, L);
         return TG_ERR_ARG;
@@ -1578,7 +1601,7 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         return TG_ERR_ARG;
     }
     if (N == 0) return TG_OK;
-    const size_t need = ws_bytes(w, NL, L, sentences ? B : 0);
+    const size_t need = call_bytes(w, NL, L, sentences ? B : 0) + (fo.weights_ws ? 0 : weights_bytes(w, L));
     if (!workspace || workspace_bytes < need) {
         tg_set_error("tg_dis_score: workspace too small (%zu < %zu)", workspace_bytes, need);
         return TG_ERR_WORKSPACE;
@@ -1587,7 +1610,8 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
     const int nchunk = (w->F + kHwTile - 1) / kHwTile;   // fp32 highway; the fragment highway sets its own count
     float* partial = (float*)((char*)workspace + align256(pooled_bytes(w, NL)));
     float* cv = (float*)((char*)partial + align256(sizeof(float) * (size_t)NL * hw_nchunk(w) * kMaxOut));
-    _Float16* w16 = (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
+    _Float16* w16 = fo.weights_ws ? (_Float16*)fo.weights_ws
+                                  : (_Float16*)((char*)cv + align256(sizeof(float) * (size_t)(sentences ? B : 0) * L * w->F));
     void* scal = (char*)w16 + align256(2 * sizeof(_Float16) * conv_weight_count(w));
     _Float16* hw16 = (_Float16*)((char*)scal + 256);
     float* padpool = (float*)((char*)hw16 + align256(hw_weight_bytes(w)));
@@ -1613,6 +1637,12 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
                            reinterpret_cast<uintptr_t>(dropout_uniforms) | reinterpret_cast<uintptr_t>(feature_out);
     const bool frag = ca.w16 != nullptr && (w->F & 7) == 0 && (al16 & 15) == 0 && (size_t)N < ((size_t)1 << 31) - 256;
     const int KB = hw_kb(w->F), MBp = hw_mb(w->F);
+    if (fo.mode == FeatOpts::kPadOnly) {   // another call workspace beside an already prepared one: its k padding
+        if (frag)
+            hipLaunchKernelGGL(k_pf_zero_pad, dim3(64), dim3(256), 0, stream, reinterpret_cast<f16x8*>(pooled),
+                               (int)hw_rb(NL), KB, w->F);
+        return TG_OK;
+    }
     if (ca.w16 && !reuse) {
         rc = launch_prepare(sa, w, scal, frag ? hw16 : nullptr, pooled, NL, stream);
         if (rc) return rc;
@@ -1621,6 +1651,31 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         ca.pfrag = reinterpret_cast<_Float16*>(pooled);
         ca.KBp = KB;
     }
+    if (!sentences && valid_len >= 0) {
+        // tg_dis_features: the windows that start at or behind valid_len are all padding and the same for every
+        // sequence -- their pooled value comes from one pass over a single all-padding sequence (same kernel, same
+        // arithmetic, so the features are the bits a pass over all windows gives), once per prepared workspace
+        if (!reuse) {
+            ConvArgs cp = ca;
+            size_t smp = 0;
+            rc = prepare_conv(cp, w, 1, L, &smp, 8);
+            if (rc) return rc;
+            if (hipMemsetAsync(padtok, 0, sizeof(int64_t) * L, stream) != hipSuccess) {
+                tg_set_error("hipMemsetAsync failed");
+                return TG_ERR_LAUNCH;
+            }
+            cp.seqs = padtok;
+            cp.N = 1;
+            cp.valid_len = L;
+            cp.padpool = nullptr;
+            cp.pfrag = nullptr;      // fp32 [1, F]
+            cp.pooled = padpool;
+            rc = launch_conv<kConvPlain>(cp, smp, stream);
+            if (rc) return rc;
+        }
+        ca.padpool = padpool;
+    }
+    if (fo.mode == FeatOpts::kPrepareOnly) return TG_OK;
     if (sentences) {
         // (1) every window of the B base sentences, (2) running max over time, (3) completions: fresh windows only
         ca.seqs = sentences;
@@ -1641,30 +1696,6 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         ca.B = B;
         rc = launch_conv<kConvPrefix>(ca, sm, stream);
     } else {
-        if (valid_len >= 0) {
-            // tg_dis_features: the windows that start at or behind valid_len are all padding and the same for every
-            // sequence -- their pooled value comes from one pass over a single all-padding sequence (same kernel, same
-            // arithmetic, so the features are the bits a pass over all windows gives), once per prepared workspace
-            if (!reuse) {
-                ConvArgs cp = ca;
-                size_t smp = 0;
-                rc = prepare_conv(cp, w, 1, L, &smp, 8);
-                if (rc) return rc;
-                if (hipMemsetAsync(padtok, 0, sizeof(int64_t) * L, stream) != hipSuccess) {
-                    tg_set_error("hipMemsetAsync failed");
-                    return TG_ERR_LAUNCH;
-                }
-                cp.seqs = padtok;
-                cp.N = 1;
-                cp.valid_len = L;
-                cp.padpool = nullptr;
-                cp.pfrag = nullptr;      // fp32 [1, F]
-                cp.pooled = padpool;
-                rc = launch_conv<kConvPlain>(cp, smp, stream);
-                if (rc) return rc;
-            }
-            ca.padpool = padpool;
-        }
         ca.seqs = seqs;
         ca.pooled = pooled;
         ca.N = N;
@@ -1877,16 +1908,48 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
 }
 
 // get_feature for the LeakGAN rollout's position loop (tg_leak.hip): tg_dis_score restricted to feature_out, reading
-// the tokens at positions >= valid_len as padding (token 0), with
-// `reuse` = the workspace already holds this call's prepared weights (same w, same N as the call that wrote them).
-int tg_dis_features(const TgDisWeights* w, const int64_t* seqs, int N, int N_layout, int L, int valid_len,
-                    float* feature_out, void* workspace, size_t workspace_bytes, bool reuse, hipStream_t stream) {
-    if (valid_len < 0 || valid_len > L || N_layout < N) {
-        tg_set_error("tg_dis_features: valid_len %d outside [0, %d] or N_layout %d < N %d", valid_len, L, N_layout, N);
+// the tokens at positions >= valid_len as padding (token 0).  The prepared weights live in weights_ws, shared by any
+// number of per-call workspaces (each laid out for N_layout sequences): tg_dis_features_prepare once per (w, N_layout),
+// on a stream every later call is ordered behind.
+size_t tg_dis_features_weights_bytes(const TgDisWeights* w, int L) { return w && L >= 1 ? weights_bytes(w, L) : 0; }
+size_t tg_dis_features_call_bytes(const TgDisWeights* w, int N_layout, int L) {
+    return w && N_layout >= 1 && L >= 1 ? call_bytes(w, N_layout, L, 0) : 0;
+}
+
+int tg_dis_features_prepare(const TgDisWeights* w, int N_layout, int L, float* feature_out, void* const* call_ws, int n_ws,
+                            size_t call_ws_bytes, void* weights_ws, hipStream_t stream) {
+    if (!call_ws || n_ws < 1 || !weights_ws || N_layout < 1) {
+        tg_set_error("tg_dis_features_prepare: bad arguments");
         return TG_ERR_ARG;
     }
-    return score_impl(w, seqs, N, L, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, feature_out, workspace,
-                      workspace_bytes, stream, reuse, valid_len, N_layout);
+    for (int q = 0; q < n_ws; ++q) {
+        FeatOpts fo;
+        fo.valid_len = L;
+        fo.N_layout = N_layout;
+        fo.weights_ws = weights_ws;
+        fo.mode = q == 0 ? FeatOpts::kPrepareOnly : FeatOpts::kPadOnly;
+        // no sequence is read in these modes: any non-null pointer passes the argument check
+        const int rc = score_impl(w, reinterpret_cast<const int64_t*>(weights_ws), N_layout, L, nullptr, 0, 0, 0.f, nullptr,
+                                  nullptr, nullptr, feature_out, call_ws[q], call_ws_bytes, stream, fo);
+        if (rc) return rc;
+    }
+    return TG_OK;
+}
+
+int tg_dis_features(const TgDisWeights* w, const int64_t* seqs, int N, int N_layout, int L, int valid_len,
+                    float* feature_out, void* call_ws, size_t call_ws_bytes, void* weights_ws, hipStream_t stream) {
+    if (valid_len < 0 || valid_len > L || N_layout < N || !weights_ws) {
+        tg_set_error("tg_dis_features: valid_len %d outside [0, %d], N_layout %d < N %d or no weights workspace", valid_len,
+                     L, N_layout, N);
+        return TG_ERR_ARG;
+    }
+    FeatOpts fo;
+    fo.reuse = true;
+    fo.valid_len = valid_len;
+    fo.N_layout = N_layout;
+    fo.weights_ws = weights_ws;
+    return score_impl(w, seqs, N, L, nullptr, 0, 0, 0.f, nullptr, nullptr, nullptr, feature_out, call_ws, call_ws_bytes,
+                      stream, fo);
 }
 
 extern "C" size_t tg_dis_score_rollout_workspace_bytes(const TgDisWeights* w, int B, int L, int R) {

@@ -46,6 +46,7 @@ constexpr int kMaxT = 64;       // given_num values per call
 constexpr int kNSpan = 8;       // canonical sampler: spans per row
 constexpr int kMaxHLeak = 128;
 constexpr int kMaxDevices = 64;
+constexpr int kFeatSets = 4;     // feature buffers and scorer call workspaces: positions p, p+1, .. p+3 in flight
 
 // per device: the three side streams of a call (feature passes of even / odd positions, manager cells) and the events
 // that order them against each other and the caller's stream
@@ -719,7 +720,8 @@ __global__ __launch_bounds__(256) void k_leak_proj(LeakArgs a) {
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LeakLayout {
-    size_t fed, tok, feat, hw, cw, hm, cm, rg, ring, z, mpre, logits, prep, dis, total;
+    size_t fed, tok, feat, hw, cw, hm, cm, rg, ring, z, mpre, logits, prep, dis_w, dis, total;
+    size_t dis_call;   // bytes of one scorer call workspace
     int rows;  // rows of one chunk
 };
 
@@ -744,7 +746,7 @@ LeakLayout layout(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, i
     o.rows = (int)N;
     o.fed = take(N * L * sizeof(int64_t));
     o.tok = take(N * sizeof(int64_t));
-    o.feat = take(2 * N * g->G * sizeof(float));   // even / odd positions
+    o.feat = take(kFeatSets * N * g->G * sizeof(float));   // one per position in flight
     o.hw = take(N * H * sizeof(float));
     o.cw = take(N * H * sizeof(float));
     o.hm = take(N * H * sizeof(float));
@@ -755,7 +757,9 @@ LeakLayout layout(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, i
     o.mpre = take(N * (size_t)4 * H * sizeof(float));
     o.logits = take(N * (size_t)g->V * sizeof(float));
     o.prep = take(((size_t)K * H + K + (size_t)H * H + H + 1 + (size_t)B * K) * sizeof(double));
-    o.dis = take(2 * al256(tg_dis_workspace_bytes(d, (int)N, L)));   // even / odd positions
+    o.dis_w = take(tg_dis_features_weights_bytes(d, L));
+    o.dis_call = al256(tg_dis_features_call_bytes(d, (int)N, L));
+    o.dis = take(kFeatSets * o.dis_call);
     o.total = off;
     return o;
 }
@@ -924,6 +928,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
         if (side && (!e || hipStreamWaitEvent(s, e, 0) != hipSuccess)) ev_fail = true;
     };
     const size_t ev_draw = 0, ev_feat = (size_t)L, ev_mgr = 2 * (size_t)L;   // one event per position each
+    const size_t ev_fork = 3 * (size_t)L, ev_prep = ev_fork + 1;
 
     const int n_prep = K * H + K + H * H + H + 1 + B * K;
     hipLaunchKernelGGL(k_leak_prep, dim3(n_prep), dim3(64), 0, stream, *g, B,
@@ -935,8 +940,9 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     int last_update = -1;
     for (int p = 1; p <= L - 3; ++p)
         if (p % g->step_size == 0) last_update = p;
-    const size_t dis_bytes = tg_dis_workspace_bytes(d, lo.rows, L);
-    int prepared_n[2] = {-1, -1};   // row count the scorer's prepared weights in each of the two workspaces were laid out for
+    int prepared_n = -1;     // row count the scorer's workspaces were prepared for
+    void* call_ws[kFeatSets];
+    for (int q = 0; q < kFeatSets; ++q) call_ws[q] = ws + lo.dis + q * lo.dis_call;
     for (int i0 = i_lo; i0 < i_hi; i0 += ci) {
         const int ni = (i_hi - i0 < ci) ? i_hi - i0 : ci;
         a.i0 = i0;
@@ -944,12 +950,23 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
         a.Nmax = B + ni * T * B;
         a.N = a.Nmax;
         float* rgbuf[2] = {reinterpret_cast<float*>(ws + lo.rg), reinterpret_cast<float*>(ws + lo.rg) + (size_t)a.Nmax * K};
-        float* featbuf[2] = {reinterpret_cast<float*>(ws + lo.feat),
-                             reinterpret_cast<float*>(ws + lo.feat) + (size_t)a.Nmax * g->G};
+        float* featbuf[kFeatSets];
+        for (int q = 0; q < kFeatSets; ++q) featbuf[q] = reinterpret_cast<float*>(ws + lo.feat) + (size_t)q * a.Nmax * g->G;
         a.rg_rd = rgbuf[0];
         a.rg_wr = rgbuf[0];
         a.feat = featbuf[0];
         hipLaunchKernelGGL(k_leak_init, dim3(a.Nmax), dim3(256), 0, stream, a);
+        if (last_update >= 0 && prepared_n != a.Nmax) {
+            // the scorer's weights, once for all the call workspaces, on the first feature stream -- behind whatever
+            // the caller's stream did with this memory before; the other feature stream waits for it once
+            record(ev_fork, stream);
+            wait(fstream[0], ev_fork);
+            rc = tg_dis_features_prepare(d, a.Nmax, L, featbuf[0], call_ws, kFeatSets, lo.dis_call, ws + lo.dis_w, fstream[0]);
+            if (rc) return rc;
+            record(ev_prep, fstream[0]);
+            wait(fstream[1], ev_prep);
+            prepared_n = a.Nmax;
+        }
         // rows taking part at a position: the leaders and the rows whose given_num it has reached (row_ids)
         auto n_live = [&](int pos) {
             int groups = 0;
@@ -965,7 +982,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
             a.N = n_live(pos);
             a.rg_rd = rgbuf[epoch_at(pos) & 1];
             a.rg_wr = rgbuf[(epoch_at(pos) + 1) & 1];
-            a.feat = featbuf[pos & 1];
+            a.feat = featbuf[pos % kFeatSets];
         };
         auto tokens_pass = [&](int pos) {
             at(pos);
@@ -997,16 +1014,14 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
         auto manager_pass = [&](int pos) -> int {
             at(pos);
             // the feature of the tokens up to pos: needs this position's draw; its output buffer and workspace were
-            // last used by position pos - 2, whose manager pass must be through with them.  Tokens behind pos are read
-            // as padding whatever the draws running ahead have written there by now.
+            // last used by position pos - kFeatSets, whose manager pass must be through with them.  Tokens behind pos
+            // are read as padding whatever the draws running ahead have written there by now.
             hipStream_t fs = fstream[pos & 1];
             wait(fs, ev_draw + pos);
-            if (pos >= 2) wait(fs, ev_mgr + pos - 2);
-            const int rc2 = tg_dis_features(d, a.fed, a.N, a.Nmax, L, pos + 1, a.feat,
-                                            ws + lo.dis + (pos & 1) * al256(dis_bytes), dis_bytes,
-                                            prepared_n[pos & 1] == a.Nmax, fs);
+            if (pos >= kFeatSets) wait(fs, ev_mgr + pos - kFeatSets);
+            const int rc2 = tg_dis_features(d, a.fed, a.N, a.Nmax, L, pos + 1, a.feat, call_ws[pos % kFeatSets],
+                                            lo.dis_call, ws + lo.dis_w, fs);
             if (rc2) return rc2;
-            prepared_n[pos & 1] = a.Nmax;
             record(ev_feat + pos, fs);
             wait(mstream, ev_feat + pos);
             const int joined = pos > 0 ? n_live(pos - 1) : B;
