@@ -351,7 +351,13 @@ int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
  *   completions [R,T,B,L]   int64; only i in [i_lo, i_hi) is written
  *   workspace   tg_leak_rollout_workspace_bytes(g, d, B, L, T, i_hi - i_lo) bytes
  * Supported: hidden size a multiple of 32 up to 128, goal_size <= 64, V <= 65536, B <= goal_init's rows; the scorer
- * as in tg_dis_score (d->precision selects its arithmetic; the generator side is fp32 MFMA / fp64). */
+ * as in tg_dis_score (d->precision selects its arithmetic; the generator side is fp32 MFMA / fp64).
+ * Streams: the call is ordered on `stream` like every other entry point (inputs must be ready on it, the completions
+ * are complete on it), but part of its work runs on three streams the library creates per device on first use and
+ * keeps (the feature passes and the manager's cells run beside the tokens' chain; events tie them to `stream`).
+ * Calls on one device take turns while they enqueue (a mutex; the GPU work of two calls may overlap if their streams
+ * allow it).  The environment variable TG_LEAK_ONE_STREAM=1 keeps everything on `stream` (same results, slower).
+ * Not exercised under stream capture. */
 typedef struct TgLeakWeights {
     const float* emb;       /* embeddings.weight     [V,E]    */
     const float* w_wih;     /* worker.weight_ih_l0   [4H,E]   */

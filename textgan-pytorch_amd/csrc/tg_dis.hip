@@ -1465,8 +1465,8 @@ __global__ __launch_bounds__(256) void k_pf_zero_pad(f16x8* Pf, int RB, int KB, 
 
 // Split-fp16 preparation (every call: the weights are live module parameters): |max| of the embedding table and
 // of all conv banks, the two power-of-two scales, and the (hi, lo) halves of the conv weights.
-// reuse: the workspace still holds the scales and halves an earlier call wrote for the SAME weights and N (the
-// position loop of tg_leak_rollout): only the offsets are recomputed.
+// This function lays the pieces out (offsets into w16, the kernel arguments); launch_prepare fills them -- skipped when
+// the workspace still holds what an earlier call wrote for the same weights (FeatOpts::reuse).
 void prepare_split(ConvArgs& ca, const TgDisWeights* w, _Float16* w16, void* scal, SplitArgs& sa) {
     float* scales = (float*)((char*)scal + 16);  // {scale_w, scale_e, 1/(scale_w*scale_e), -} x 2 (conv, highway)
     sa = SplitArgs{};

@@ -17,9 +17,10 @@
 // nothing from it, and the feature passes of different positions need nothing from each other (only the manager's
 // cells are a chain).  At run_leakgan.py's shape every kernel here is a few dozen workgroups -- latency, not
 // throughput -- so the call spreads over four streams: the caller's (tokens' chain), two of the device's own for the
-// feature passes of even and odd positions (each with its own scorer workspace and feature buffer), one for the
-// manager's cells; events order them (draw(pos) -> feature(pos) -> manager(pos) -> worker(pos + 1) where pos rebuilt
-// the goal; manager(pos - 2) -> feature(pos) for the buffers).  rg is a pair of buffers (the one in force, the one being
+// feature passes of even and odd positions, one for the manager's cells; events order them (draw(pos) ->
+// feature(pos) -> manager(pos) -> worker(pos + 1) where pos rebuilt the goal).  Feature buffers and scorer call
+// workspaces come in sets of kFeatSets, used round-robin by position (manager(pos - kFeatSets) -> feature(pos) for
+// their reuse); the scorer's prepared weights are shared by all sets and written once per call.  rg is a pair of buffers (the one in force, the one being
 // rebuilt) and the feature pass reads positions > pos as padding by argument, so no stream reads what another is
 // writing.  Manager passes behind the last rebuild that a worker pass still reads are not run.  Results do not depend
 // on the spread: TG_LEAK_ONE_STREAM=1 puts everything on the caller's stream (same bits, for timing comparisons).
