@@ -265,6 +265,21 @@ int tg_dis_score_rollout(const TgDisWeights* w, const int64_t* sentences,
                          int col, float dropout_p,
                          const float* dropout_uniforms, float* reward_out,
                          void* workspace, size_t workspace_bytes, void* stream);
+/* tg_dis_score_rollout in two calls on the same workspace, same results to the bit.  ..._prepare does what needs only
+ * D's parameters and the sentences (models/discriminator.py:40-64 reads neither anything else nor the completions for
+ * it: the weights' preparation, the sentences' window values and their running maxima); ..._prepared does the rest.
+ * ROLLOUT.get_reward (utils/rollout.py:128-154) calls gen and dis one after the other; with the split the first part
+ * can be enqueued on a second stream beside the generator's kernels (rollout.py of the shim does).  The caller orders
+ * the two calls (and any earlier use of the workspace memory) itself.  dropout_uniforms: the pointer the second call
+ * will pass (its alignment decides which highway kernel the weights are prepared for), or NULL. */
+int tg_dis_score_rollout_prepare(const TgDisWeights* w, const int64_t* sentences, int B, int L, int R,
+                                 const float* dropout_uniforms, void* workspace, size_t workspace_bytes,
+                                 void* stream);
+int tg_dis_score_rollout_prepared(const TgDisWeights* w, const int64_t* sentences,
+                                  const int64_t* completions, int B, int L, int R,
+                                  int col, float dropout_p,
+                                  const float* dropout_uniforms, float* reward_out,
+                                  void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Dropout-only re-scoring (MaliGAN reward).

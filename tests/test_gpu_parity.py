@@ -551,6 +551,38 @@ def test_prefix_reuse_scorer_is_bit_identical(name, precision):
     np.testing.assert_allclose(fast.cpu().numpy(), c["raw"], atol=1e-4, rtol=0)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "split_f16"])
+def test_scorer_preparation_beside_the_generator_gives_the_same_bits(precision):
+    """ROLLOUT.get_reward enqueues the scorer's preparation (tg_dis_score_rollout_prepare: weight pieces, the sentences'
+    window values) on a second stream beside the generator and finishes with tg_dis_score_rollout_prepared: the rewards
+    are those of the one-call path to the bit, with live dropout from explicit uniforms, call after call (the side
+    stream's workspace is handed back and reused), and on a misaligned dropout tensor (exact-fp32 highway)."""
+    c = _cases.load("reward_c1_r2")
+    gen, dis = _gen(c), _dis(c)
+    dis.train()
+    sent, u, _ = _cases.reward_inputs(c)
+    R, L, B = int(c["R"]), int(c["L"]), int(c["B"])
+    F = int(tg._lib.dis_weights(dis, precision)[0].F)
+    du = _t(synth.uniform01(17, (R * L * B * F + 1,)))
+    ro = tg.ROLLOUT(gen)
+    ro.dis_precision = precision
+    for dropout_uniforms in (du[:-1].view(R * L, B, F), du[1:].view(R * L, B, F)):   # 16-byte aligned / off by 4 bytes
+        ro.overlap_prepare = False
+        want = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), dropout_uniforms=dropout_uniforms, return_parts=True)
+        ro.overlap_prepare = True
+        for _ in range(3):
+            got = ro.get_reward(_t(sent), R, dis, uniforms=_t(u), dropout_uniforms=dropout_uniforms, return_parts=True)
+            assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0]) and torch.equal(got[2], want[2])
+    # the two halves called by hand, with the preparation on the current stream
+    w = tg._lib.dis_weights(dis, precision)
+    ws = tg.ops.dis_score_rollout_prepare(dis, _t(sent), R, weights=w)
+    raw = tg.ops.dis_score_rollout(dis, _t(sent), want[2], col=1, dropout_p=float(dis.dropout.p),
+                                   dropout_uniforms=du[:-1].view(R * L * B, F), weights=w, prepared=ws)
+    ro.overlap_prepare = False
+    assert torch.equal(raw, ro.get_reward(_t(sent), R, dis, uniforms=_t(u), dropout_uniforms=du[:-1].view(R * L, B, F),
+                                          return_parts=True)[1])
+
+
 def test_split_precision_against_fp32():
     """The default split-fp16 x3 scorer against the exact-fp32 scorer on the same inputs at C2's shape: pooled
     features / logits within 2e-5 relative (measured ~2e-6), rewards within 1e-5."""

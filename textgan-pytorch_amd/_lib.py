@@ -20,7 +20,8 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
            "tg_gen_sample_static_bytes", "tg_gen_sample_static",
            "tg_dis_workspace_bytes",
-           "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_rescore_dropout",
+           "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_score_rollout_prepare",
+           "tg_dis_score_rollout_prepared", "tg_dis_rescore_dropout",
            "tg_gen_nll_workspace_bytes", "tg_gen_nll", "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
            "tg_leak_rollout_workspace_bytes", "tg_leak_rollout",
            "tg_reward_reduce", "tg_allgather_rows",
@@ -97,6 +98,11 @@ def lib():
         l.tg_dis_score_rollout.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float] + [C.c_void_p] * 3 + \
                                           [C.c_size_t, C.c_void_p]
         l.tg_dis_score_rollout.restype = C.c_int
+        l.tg_dis_score_rollout_prepared.argtypes = l.tg_dis_score_rollout.argtypes
+        l.tg_dis_score_rollout_prepared.restype = C.c_int
+        l.tg_dis_score_rollout_prepare.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                                   C.c_size_t, C.c_void_p]
+        l.tg_dis_score_rollout_prepare.restype = C.c_int
         l.tg_dis_rescore_dropout.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                              C.c_void_p, C.c_void_p]
         l.tg_dis_rescore_dropout.restype = C.c_int

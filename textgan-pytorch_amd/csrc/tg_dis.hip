@@ -1675,17 +1675,27 @@ int score_impl(const TgDisWeights* w, const int64_t* seqs, int N, int L, const i
         }
         ca.padpool = padpool;
     }
-    if (fo.mode == FeatOpts::kPrepareOnly) return TG_OK;
+    if (fo.mode == FeatOpts::kPrepareOnly && !sentences) return TG_OK;
     if (sentences) {
         // (1) every window of the B base sentences, (2) running max over time, (3) completions: fresh windows only
-        ca.seqs = sentences;
-        ca.N = B;
-        ca.cv = cv;
-        rc = launch_conv<kConvStoreAll>(ca, sm, stream);
-        if (rc) return rc;
-        tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
-        hipLaunchKernelGGL(k_dis_prefix_scan, dim3((B * w->F + 255) / 256), dim3(256), 0, stream, cv, B, L, w->F);
-        tg_prof_end(stream);
+        if (!reuse) {
+            ca.seqs = sentences;
+            ca.N = B;
+            ca.cv = cv;
+            rc = launch_conv<kConvStoreAll>(ca, sm, stream);
+            if (rc) return rc;
+            tg_prof_begin(TG_KERNEL_DIS_PREFIX, stream);
+            hipLaunchKernelGGL(k_dis_prefix_scan, dim3((B * w->F + 255) / 256), dim3(256), 0, stream, cv, B, L, w->F);
+            tg_prof_end(stream);
+        }
+        if (fo.mode == FeatOpts::kPrepareOnly) {   // everything that needs the weights and the sentences only
+            hipError_t e0 = hipGetLastError();
+            if (e0 != hipSuccess) {
+                tg_set_error("tg_dis_score_rollout_prepare launch: %s", hipGetErrorString(e0));
+                return TG_ERR_LAUNCH;
+            }
+            return TG_OK;
+        }
         rc = prepare_conv(ca, w, N, L, &sm, 8);
         if (rc) return rc;
         ca.valid_len = L;
@@ -1967,4 +1977,36 @@ extern "C" int tg_dis_score_rollout(const TgDisWeights* w, const int64_t* senten
     }
     return score_impl(w, completions, R * L * B, L, sentences, B, col, dropout_p, dropout_uniforms, reward_out,
                       nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// tg_dis_score_rollout in two parts: what needs only the weights and the sentences (|max|, scales, weight pieces, the
+// sentences' window values and their running maxima), and the rest.  The first part can run beside the generator.
+extern "C" int tg_dis_score_rollout_prepare(const TgDisWeights* w, const int64_t* sentences, int B, int L, int R,
+                                            const float* dropout_uniforms, void* workspace, size_t workspace_bytes,
+                                            void* stream) {
+    if (B == 0 && R >= 0 && L >= 1) return TG_OK;
+    if (!sentences || B < 1 || R < 1 || (long)R * L * B > 0x7fffffffL) {
+        tg_set_error("tg_dis_score_rollout_prepare: bad arguments (B=%d L=%d R=%d)", B, L, R);
+        return TG_ERR_ARG;
+    }
+    FeatOpts fo;
+    fo.mode = FeatOpts::kPrepareOnly;
+    // no completion is read in this mode: the sentences stand in for the pointer check
+    return score_impl(w, sentences, R * L * B, L, sentences, B, 0, 0.f, dropout_uniforms, nullptr, nullptr, nullptr,
+                      workspace, workspace_bytes, (hipStream_t)stream, fo);
+}
+
+extern "C" int tg_dis_score_rollout_prepared(const TgDisWeights* w, const int64_t* sentences, const int64_t* completions,
+                                             int B, int L, int R, int col, float dropout_p,
+                                             const float* dropout_uniforms, float* reward_out, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    if (B == 0 && R >= 0 && L >= 1) return TG_OK;
+    if (!sentences || B < 1 || R < 0 || (long)R * L * B > 0x7fffffffL) {
+        tg_set_error("tg_dis_score_rollout_prepared: bad arguments (B=%d L=%d R=%d)", B, L, R);
+        return TG_ERR_ARG;
+    }
+    FeatOpts fo;
+    fo.reuse = true;
+    return score_impl(w, completions, R * L * B, L, sentences, B, col, dropout_p, dropout_uniforms, reward_out,
+                      nullptr, nullptr, workspace, workspace_bytes, (hipStream_t)stream, fo);
 }

@@ -243,11 +243,28 @@ def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_rewar
 
 
 @_on_device
+def dis_score_rollout_prepare(dis, sentences, R, dropout_uniforms=None, weights=None, precision=None):
+    """tg_dis_score_rollout_prepare: the part of the rollout scorer that needs only D's parameters and the sentences,
+    enqueued on the current stream.  Returns the workspace to hand to dis_score_rollout(..., prepared=ws); the caller
+    orders the two calls (ROLLOUT.get_reward runs this one on a second stream beside the generator)."""
+    w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
+    s, _ = _tokens(sentences, "sentences")
+    B, L = s.shape
+    nbytes = _lib.lib().tg_dis_score_rollout_workspace_bytes(C.byref(w), B, L, R)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=s.device)
+    du = None if dropout_uniforms is None else _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms")
+    _lib.check(_lib.lib().tg_dis_score_rollout_prepare(
+        C.byref(w), _lib.dev_ptr(s, I64, "sentences"), B, L, R, du, _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return ws
+
+
+@_on_device
 def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout_uniforms=None, reward_out=None,
-                      weights=None, precision=None, dropout_seed=None):
+                      weights=None, precision=None, dropout_seed=None, prepared=None):
     """tg_dis_score_rollout: the scorer over tg_gen_rollout's [R,L,B,L] completions with prefix reuse
     (windows inside the tokens a completion shares with its sentence are evaluated once per sentence).
-    Returns raw reward rows [R*L, B]."""
+    Returns raw reward rows [R*L, B].  prepared: the workspace dis_score_rollout_prepare returned for the same D,
+    sentences and R (tg_dis_score_rollout_prepared then runs the rest)."""
     w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
     s, _ = _tokens(sentences, "sentences")
     comp, _ = _tokens(completions, "completions")
@@ -258,8 +275,12 @@ def dis_score_rollout(dis, sentences, completions, col=1, dropout_p=0.0, dropout
     reward = reward_out if reward_out is not None else torch.empty(R * L, B, dtype=F32, device=dev)
     du = _dropout_args(w, R * L * B, dropout_p, dropout_uniforms, dropout_seed, R * L * B * w.F)
     nbytes = _lib.lib().tg_dis_score_rollout_workspace_bytes(C.byref(w), B, L, R)
-    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().tg_dis_score_rollout(
+    if prepared is not None and prepared.numel() < nbytes:
+        raise RuntimeError("textgan_hip: the prepared workspace holds %d bytes, this call needs %d"
+                           % (prepared.numel(), nbytes))
+    ws = prepared if prepared is not None else torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    fn = _lib.lib().tg_dis_score_rollout_prepared if prepared is not None else _lib.lib().tg_dis_score_rollout
+    _lib.check(fn(
         C.byref(w), _lib.dev_ptr(s, I64, "sentences"), _lib.dev_ptr(comp, I64, "completions"), B, L, R, int(col),
         float(dropout_p), du, _lib.dev_ptr(reward, F32, "reward"),
         _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))

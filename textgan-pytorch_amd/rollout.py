@@ -31,6 +31,10 @@ class ROLLOUT:
     #: explicit tg.dist.sync_weights).  The value must be the same on every rank of the group: it decides whether a
     #: collective is entered.
     sync_weights = True
+    #: get_reward enqueues the scorer's preparation (what needs only D's parameters and the sentences: weight pieces,
+    #: the sentences' window values) on a second stream, beside the generator's kernels.  Same results to the bit;
+    #: False keeps the whole call on the current stream.
+    overlap_prepare = True
 
     def __init__(self, gen, gpu=True):
         self.gen = gen
@@ -44,6 +48,7 @@ class ROLLOUT:
         self.group = None               # sharding is opt-in: tg.dist.WORLD (default group) or a ProcessGroup
         self._rank_gens = {}            # (device, rank) -> torch.Generator of a sharded call's private uniforms
         self.timers = None              # optional dict name -> list[(start_event, end_event)]
+        self._side = {}                 # device -> torch.cuda.Stream of the scorer's preparation
         _lib.lib()                      # fail loudly here if the HIP extension is missing
 
     @property
@@ -134,8 +139,6 @@ class ROLLOUT:
             raw_local = torch.empty(Rl * L, B, dtype=torch.float32, device=dev)
             comp = torch.empty(0, L, B, L, dtype=torch.int64, device=dev)   # a rank that owns no rollout index
             if Rl > 0:
-                with self._timed("gen_rollout"):
-                    comp = ops.gen_rollout(self.gen, sentences, Rl, u, precision=self.gen_precision)
                 p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
                 weights = _lib.dis_weights(dis, self.dis_precision)
                 F = weights[0].F
@@ -144,6 +147,30 @@ class ROLLOUT:
                     du_all = dropout_uniforms.reshape(R * L * B, F)[plan.i_lo * L * B:plan.i_hi * L * B]
                 # whole rollouts per scorer call, at most dis_chunk sequences each
                 step = max(1, self.dis_chunk // max(1, L * B))
+                prepared = None
+                overlap = self.overlap_prepare and step >= Rl
+                if overlap:
+                    # one scorer call: its preparation goes to a second stream and runs beside the generator.  That
+                    # stream starts behind everything the current one holds so far (the parameters, the sentences,
+                    # whoever held the workspace's memory before); the generator is enqueued first, so its persistent
+                    # workgroups are on the chip before the preparation's small kernels ask for room.
+                    cur = torch.cuda.current_stream(dev)
+                    side = self._side.get(dev)
+                    if side is None:
+                        side = self._side[dev] = torch.cuda.Stream(dev)
+                    if du_all is not None:
+                        du_all = du_all.contiguous()
+                    fork = torch.cuda.Event()
+                    fork.record(cur)
+                with self._timed("gen_rollout"):
+                    comp = ops.gen_rollout(self.gen, sentences, Rl, u, precision=self.gen_precision)
+                if overlap:
+                    side.wait_event(fork)
+                    with torch.cuda.stream(side):
+                        prepared = ops.dis_score_rollout_prepare(dis, sentences, Rl, dropout_uniforms=du_all,
+                                                                 weights=weights)
+                    cur.wait_stream(side)
+                    prepared.record_stream(cur)
                 with self._timed("dis_score"):
                     for lo in range(0, Rl, step):
                         hi = min(Rl, lo + step)
@@ -156,7 +183,7 @@ class ROLLOUT:
                             seed = _lib.next_dropout_seed(plan.rank)
                         ops.dis_score_rollout(dis, sentences, comp[lo:hi], col=current_k + 1, dropout_p=p,
                                               dropout_uniforms=du, reward_out=raw_local[lo * L:hi * L],
-                                              weights=weights, dropout_seed=seed)
+                                              weights=weights, dropout_seed=seed, prepared=prepared)
             with self._timed("exchange"):
                 raw = tdist.gather_rows(raw_local, plan, L, self.group)
             with self._timed("reduce"):
