@@ -971,7 +971,8 @@ def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, monkeypatch):
     unsorted, repeated and equal to L gives, for each of them, exactly the rows the plain ascending call gives for that
     given_num under the same uniforms (the sentence itself for given_num = L); and the call with everything on one
     stream (TG_LEAK_ONE_STREAM=1) gives the same bits.  H = 32 takes the worker cell inside the draw kernel, H = 64 the
-    kernel of its own; TG_LEAK_SPLIT_CELL=1 forces the latter (different summation order: rows agree up to CDF ties)."""
+    kernel of its own; TG_LEAK_SPLIT_CELL=1 forces the latter (different summation order: rows agree up to CDF ties).
+    A call cut into several chunks of the rollout index (each with its own leaders) gives the same bits too."""
     V, E, K, L, B, R, step = 300, 32, 16, 20, 7, 3, 4
     gsd = synth.leak_state(V, E, H, K, 1720, B, seed=5, std=0.2)
     dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=5)
@@ -996,6 +997,10 @@ def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, monkeypatch):
     monkeypatch.setenv("TG_LEAK_ONE_STREAM", "1")
     assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u)), std)
     monkeypatch.delenv("TG_LEAK_ONE_STREAM")
+    # several chunks of the rollout index in one call (TG_LEAK_LOGITS_BYTES: room for one rollout index per chunk)
+    monkeypatch.setenv("TG_LEAK_LOGITS_BYTES", str((B + T * B) * V * 4))
+    assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u)), std)
+    monkeypatch.delenv("TG_LEAK_LOGITS_BYTES")
     monkeypatch.setenv("TG_LEAK_SPLIT_CELL", "1")
     other = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u))
     assert (other == std).all(-1).float().mean() >= 0.97

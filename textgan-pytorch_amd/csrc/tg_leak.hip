@@ -731,7 +731,12 @@ int span_len(int V) { return 16 * ((V + kNSpan * 16 - 1) / (kNSpan * 16)); }
 // rows per chunk: the B leaders and whole rollout indices (T*B rows each), logits of a chunk at most ~1 GiB
 int chunk_indices(const TgLeakWeights* g, int B, int T, int n_i) {
     const size_t per_i = (size_t)T * B, row = g->V * sizeof(float);
-    const size_t room = ((size_t)1 << 30) / row;
+    size_t budget = (size_t)1 << 30;
+    if (const char* e = getenv("TG_LEAK_LOGITS_BYTES")) {   // diagnostic: a small budget forces several chunks
+        const unsigned long long v = strtoull(e, nullptr, 10);
+        if (v > 0) budget = (size_t)v;
+    }
+    const size_t room = budget / row;
     size_t fit = room > (size_t)B ? (room - B) / per_i : 0;
     if (fit < 1) fit = 1;
     return (int)(fit < (size_t)n_i ? fit : (size_t)n_i);
