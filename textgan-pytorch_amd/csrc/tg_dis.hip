@@ -349,8 +349,13 @@ __global__ __launch_bounds__(kConvThreads) void k_dis_conv(const ConvArgs a) {
                 for (int ks = 0; ks < 4; ++ks) {
 #pragma unroll
                     for (int nt = 0; nt < NBC; ++nt) {
-                        const f16x8 bh = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + 16 * ks);
-                        const f16x8 bl = *reinterpret_cast<const f16x8*>(ebuf_h + boff[nt] + toff + kEd + 16 * ks);
+#if defined(TG_CONV_HALF_B)   // timing ablation only (wrong results): every second tile reuses its neighbour's operand
+                        const int ntl = nt & ~1;
+#else
+                        const int ntl = nt;
+#endif
+                        const f16x8 bh = *reinterpret_cast<const f16x8*>(ebuf_h + boff[ntl] + toff + 16 * ks);
+                        const f16x8 bl = *reinterpret_cast<const f16x8*>(ebuf_h + boff[ntl] + toff + kEd + 16 * ks);
                         acc[nt] = TG_MFMA16(cur[ks], bh, acc[nt]);
                         acc[nt] = TG_MFMA16(cur[ks], bl, acc[nt]);
                         acc[nt] = TG_MFMA16(cur[4 + ks], bh, acc[nt]);
