@@ -397,6 +397,7 @@ def bench_leak(args, dev):
     sent = torch.from_numpy(tg.synth.tokens(1, (B, L), V)).to(dev)
     ro = tg.ROLLOUT(gen, True)
     ro.dis_precision = args.dis_precision
+    ro.gen_precision = args.gen_precision
     for _ in range(args.warmup):
         ro.get_reward_leakgan(sent, R, dis, 0)
     torch.cuda.synchronize()
@@ -423,11 +424,14 @@ def bench_leak(args, dev):
     peak = PEAK_F16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
     kernels["dis_conv"]["tflops"] = ach
     kernels["leak_proj"]["tflops"] = proj_flops / (kernels["leak_proj"]["ms_per_call"] * 1e-3) / 1e12
-    kernels["leak_proj"]["peak_tflops"] = PEAK_FP32_MFMA_TFLOPS
+    gsplit = (args.gen_precision or tg._lib.default_gen_precision) == "split_f16"
+    kernels["leak_proj"]["peak_tflops"] = PEAK_F16_MFMA_TFLOPS if gsplit else PEAK_FP32_MFMA_TFLOPS
+    kernels["leak_proj"]["mfma_products_per_flop"] = 3 if gsplit else 1
     out = {"metric": "LeakGAN MC rollout completions/sec", "value": N * args.steps / dt, "unit": "completions/s",
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "f32 (generator: fp32 MFMA, goal algebra f64; scorer: %s)" % ("split-f16 x3" if split else "f32"),
+           "dtype": "f32 (generator: %s work2goal projection, fp32 cells, goal algebra f64; scorer: %s)"
+                    % ("split-f16 x3" if gsplit else "fp32 MFMA", "split-f16 x3" if split else "f32"),
            "data": "synthetic",
            "config": {"workload": "run_leakgan.py shape: vocab %d, len %d, emb/hidden %d, goal_size %d, step_size %d, "
                                   "batch %d, rollout_num %d, LeakGAN_D%s" % (V, L, H, K, step, B, R,
@@ -436,8 +440,10 @@ def bench_leak(args, dev):
            "roofline": {"kernel": "dis_conv", "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": ach / peak, "traffic": None, "flops_per_launch": conv_f * N,
                         "avg_launch_ms": kernels["dis_conv"]["avg_ms"],
-                        "note": "every position re-scores the whole zero-padded row (the reference does the same); "
-                                "launches of 1 280 sequences do not fill the chip"},
+                        "note": "flops as the reference spends them: every position re-scores the whole zero-padded row "
+                                "of every completion.  The library evaluates the rows that differ from their "
+                                "sentence's leader and the windows that hold a token (DESIGN.md 3.7), and the "
+                                "kernel times are summed over streams that overlap"},
            "flops_per_step": {"scorer_features": feat_flops, "work2goal_projection": proj_flops},
            "kernels": kernels}
     if not args.no_cpu_baseline:

@@ -366,7 +366,11 @@ int tg_gen_pg_backward(const TgGenWeights* w, const int64_t* inp,
  *   completions [R,T,B,L]   int64; only i in [i_lo, i_hi) is written
  *   workspace   tg_leak_rollout_workspace_bytes(g, d, B, L, T, i_hi - i_lo) bytes
  * Supported: hidden size a multiple of 32 up to 128, goal_size <= 64, V <= 65536, B <= goal_init's rows; the scorer
- * as in tg_dis_score (d->precision selects its arithmetic; the generator side is fp32 MFMA / fp64).
+ * as in tg_dis_score (d->precision selects its arithmetic).  The generator side is fp32 MFMA / fp64 except the
+ * work2goal projection -- outputs[n, v] = z[n, :] . [work2goal.weight rows of v | work2goal.bias of v], 2 (K H + K) V
+ * flops per row and position, nearly all of the generator's -- which g->precision selects: TG_GEN_FP32 exact, or
+ * TG_GEN_SPLIT_F16 as three fp16 products of (hi, lo) halves with fp32 accumulation (22 mantissa bits per operand,
+ * as in tg_gen_rollout; tokens then agree with the exact path up to ties of the inverse-CDF draw).
  * Streams: the call is ordered on `stream` like every other entry point (inputs must be ready on it, the completions
  * are complete on it), but part of its work runs on three streams the library creates per device on first use and
  * keeps (the feature passes and the manager's cells run beside the tokens' chain; events tie them to `stream`).
@@ -393,6 +397,7 @@ typedef struct TgLeakWeights {
     int32_t step_size;      /* LeakGAN_G.step_size (models/LeakGAN_G.py:36) */
     int32_t B_init;         /* rows of goal_init (cfg.batch_size at construction, models/LeakGAN_G.py:48) */
     float temperature;      /* LeakGAN_G.temperature (1.5, :38): applied at positions 0 and 1 */
+    int32_t precision;      /* TG_GEN_FP32 or TG_GEN_SPLIT_F16: arithmetic of the work2goal projection (ABI 0.4) */
 } TgLeakWeights;
 size_t tg_leak_rollout_workspace_bytes(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, int T,
                                        int n_i /* rollout indices of the call: i_hi - i_lo */);

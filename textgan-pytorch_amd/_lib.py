@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TEXTGAN_HIP_LIB") or os.path.join(_HERE, "libtextgan_hip.so")
 MAX_FILTERS = 16
 MAX_OUT = 8
-ABI_VERSION = b"textgan_hip 0.3"   # include/textgan_hip.h; argument lists changed in 0.2 and 0.3
+ABI_VERSION = b"textgan_hip 0.4"   # include/textgan_hip.h; argument lists / structs changed in 0.2, 0.3, 0.4
 
 SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_forced",
            "tg_gen_teacher_forced_workspace_bytes", "tg_gen_teacher_forced_ws", "tg_gen_pg_forward_workspace_bytes",
@@ -47,7 +47,8 @@ class LeakW(C.Structure):
     """TgLeakWeights: LeakGAN_G parameters (models/LeakGAN_G.py:40-48)."""
     _fields_ = [(k, C.c_void_p) for k in ("emb", "w_wih", "w_whh", "w_bih", "w_bhh", "m_wih", "m_whh", "m_bih", "m_bhh",
                                           "w2g_w", "w2g_b", "m2g_w", "m2g_b", "g2g_w", "goal_init")] + \
-               [(k, C.c_int32) for k in ("V", "E", "H", "G", "K", "step_size", "B_init")] + [("temperature", C.c_float)]
+               [(k, C.c_int32) for k in ("V", "E", "H", "G", "K", "step_size", "B_init")] + [("temperature", C.c_float),
+                                                                                          ("precision", C.c_int32)]
 
 
 class DisW(C.Structure):
@@ -206,9 +207,10 @@ def gen_weights(gen, precision=None, teacher=False):
     return w, keep
 
 
-def leak_weights(gen):
+def leak_weights(gen, precision=None):
     """Pack the live parameters of a LeakGAN_G-shaped module (models/LeakGAN_G.py:40-48): embeddings, worker and
-    manager LSTMs, work2goal, mana2goal, goal2goal, goal_init, with step_size / temperature from the module."""
+    manager LSTMs, work2goal, mana2goal, goal2goal, goal_init, with step_size / temperature from the module.
+    precision: arithmetic of the work2goal projection, "fp32" or "split_f16" (None: default_gen_precision)."""
     names = (("embeddings.weight", gen.embeddings.weight),
              ("worker.weight_ih_l0", gen.worker.weight_ih_l0), ("worker.weight_hh_l0", gen.worker.weight_hh_l0),
              ("worker.bias_ih_l0", gen.worker.bias_ih_l0), ("worker.bias_hh_l0", gen.worker.bias_hh_l0),
@@ -228,7 +230,10 @@ def leak_weights(gen):
     if (keep[1].shape != (4 * H, E) or keep[5].shape != (4 * H, G) or keep[9].shape != (V * K, H)
             or keep[11].shape != (G, H) or keep[14].shape[1] != G):
         raise RuntimeError("textgan_hip: LeakGAN generator parameter shapes are inconsistent")
-    w = LeakW(*ptrs, V, E, H, G, K, int(gen.step_size), int(keep[14].shape[0]), float(getattr(gen, "temperature", 1.5)))
+    if (precision or default_gen_precision) not in PRECISIONS:
+        raise RuntimeError("textgan_hip: unknown precision %r" % (precision,))
+    w = LeakW(*ptrs, V, E, H, G, K, int(gen.step_size), int(keep[14].shape[0]), float(getattr(gen, "temperature", 1.5)),
+              PRECISIONS[precision or default_gen_precision])
     return w, keep
 
 

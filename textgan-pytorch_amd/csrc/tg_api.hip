@@ -92,7 +92,7 @@ extern "C" int tg_profile_read(int id, double* total_ms, int* count) {
     if (bad) (void)hipGetLastError();  // clear the sticky error of a failed event query
     return TG_OK;
 }
-extern "C" const char* tg_version(void) { return "textgan_hip 0.3 gfx950"; }
+extern "C" const char* tg_version(void) { return "textgan_hip 0.4 gfx950"; }
 
 // torch.mean(rewards.view(B, L, R), dim=-1) on the flat [R*L, B] buffer (utils/rollout.py:153):
 // out[bt] = mean_r raw[bt*R + r].  One thread per output, sequential fp32 sum (R <= a few hundred).

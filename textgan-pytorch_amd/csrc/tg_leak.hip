@@ -38,6 +38,7 @@
 
 #include "tg_common.h"
 #include "tg_dis.h"
+#include "tg_pgw.h"
 
 namespace {
 
@@ -58,6 +59,8 @@ struct LeakSide {
 std::mutex g_side_mu;
 LeakSide g_side[kMaxDevices];
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
 struct LeakArgs {
     TgLeakWeights w;
     const int64_t* sentences;  // [B,L]
@@ -71,7 +74,11 @@ struct LeakArgs {
     const float* rg_rd;        // [N,K] normalised goal2goal(real_goal) in force at this position (k_leak_worker reads)
     float* rg_wr;              // [N,K] the other half of the pair: k_leak_manager writes the next one there
     double* ring;              // [4][N][K] goal2goal(cur_goal) of the last four positions
-    float* z;                  // [N, K*H + K] projection operand
+    float* z;                  // [N, K*H + K] projection operand (exact-fp32 projection)
+    f16x8* zfrag;              // split projection: the same operand as the fragment GEMM's A pieces (tg_pgw.h), scaled
+    int zKB;                   //   by sZ; 16-wide k blocks per 32-row block
+    float sZ;
+    int split;                 // 1: TG_GEN_SPLIT_F16
     float* mpre;               // [N, 4H] manager.weight_ih . feature of this position (k_leak_mgates)
     float* logits;             // [N,V]
     const double* prep;        // P [K*H], q [K], Q [H*H], c [H], s [1], gp [B*K]
@@ -128,6 +135,54 @@ __global__ __launch_bounds__(64) void k_leak_prep(TgLeakWeights w, int B, double
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (lane == 0) prep[idx] = acc;
+}
+
+// Piece p = (k block, half) of row n of the projection operand z = temperature * [rg (x) h_w | rg] (zero past K*H + K),
+// scaled, as fp16 hi / lo halves at their place in the fragment GEMM's A operand: the operand never exists in fp32.
+__device__ __forceinline__ void z_store_frag(const LeakArgs& a, int n, int p, const float* rs, const float* hs, float temp) {
+    const int H = a.w.H, K = a.w.K, KH = K * H;
+    const int kb = p >> 1, half = p & 1, k0 = 16 * kb + 8 * half;
+    f16x8 h, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int q = k0 + e;
+        float v = 0.f;
+        if (q < KH) v = temp * rs[q / H] * hs[q % H];
+        else if (q < KH + K) v = temp * rs[q - KH];
+        const float x = v * a.sZ;
+        const _Float16 xh = (_Float16)x;
+        h[e] = xh;
+        l[e] = (_Float16)(x - (float)xh);
+    }
+    f16x8* dst = a.zfrag + (((size_t)(n >> 5) * a.zKB + kb) * 2) * 64 + (n & 31) + 32 * half;
+    dst[0] = h;
+    dst[64] = l;
+}
+
+// work2goal as one [V, K*H + K] matrix (row v: its K rows of the weight, then its K biases): the projection's B operand
+__global__ __launch_bounds__(256) void k_leak_wcat(TgLeakWeights w, float* wcat) {
+    const int KH = w.K * w.H, ld = KH + w.K;
+    const size_t total = (size_t)w.V * ld;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t v = i / ld;
+        const int q = (int)(i - v * ld);
+        wcat[i] = q < KH ? w.w2g_w[v * KH + q] : w.w2g_b[v * w.K + (q - KH)];
+    }
+}
+
+// scal[0] = sW (power of two putting |max| of wcat near 2^14), [1] = sZ, [2] = 1 / (sW sZ)
+__global__ void k_leak_scales(const unsigned* absmax, float sZ, float* scal) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float m = __uint_as_float(absmax[0]);
+    int ex = 0;
+    float sW = 1.f;
+    if (m > 0.f && m < __builtin_inff()) {
+        (void)frexpf(m, &ex);
+        sW = ldexpf(1.f, 14 - ex);
+    }
+    scal[0] = sW;
+    scal[1] = sZ;
+    scal[2] = 1.f / (sW * sZ);
 }
 
 // ---- per chunk.  Leaders: zero state, zero-padded feature input, rg = normalize(goal2goal(goal_init[b])).  The other
@@ -250,6 +305,10 @@ __device__ __forceinline__ void leak_cell_row(const LeakArgs& a, int n, int64_t 
     // z = temperature * [rg (x) h_w | rg] (k_leak_worker's expression)
     const float temp = a.pos > 1 ? 1.0f : a.w.temperature;
     const int ldz = K * H + K;
+    if (a.split) {
+        for (int p = tid; p < 2 * a.zKB; p += 256) z_store_frag(a, n, p, rs, hs, temp);
+        return;
+    }
     float* z = a.z + (size_t)n * ldz;
     for (int q = tid; q < ldz; q += 256) {
         const bool tail = q >= K * H;
@@ -532,7 +591,14 @@ __global__ __launch_bounds__(kLThreads) void k_leak_worker(LeakArgs a) {
     const int rows = tg_min(32, N - n0);
     for (int idx = tid; idx < rows * K; idx += kLThreads) g[idx] = a.rg_rd[(size_t)n0 * K + idx];   // g is free here (<= 32 x 64)
     __syncthreads();
-    for (int q = tid; q < ldz; q += kLThreads) {
+    if (a.split) {
+        const int np = 2 * a.zKB;
+        for (int idx = tid; idx < rows * np; idx += kLThreads) {
+            const int r = idx / np;
+            z_store_frag(a, n0 + r, idx - r * np, g + r * K, hl + r * (H + 1), temp);
+        }
+    }
+    for (int q = tid; q < (a.split ? 0 : ldz); q += kLThreads) {
         const bool tail = q >= K * H;
         const int kq = tail ? q - K * H : q / H, hq = tail ? 0 : q % H;
         for (int r = 0; r < rows; ++r) {
@@ -721,7 +787,7 @@ __global__ __launch_bounds__(256) void k_leak_proj(LeakArgs a) {
 inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct LeakLayout {
-    size_t fed, tok, feat, hw, cw, hm, cm, rg, ring, z, mpre, logits, prep, dis_w, dis, total;
+    size_t fed, tok, feat, hw, cw, hm, cm, rg, ring, z, mpre, logits, prep, dis_w, dis, wcat, wfrag, zfrag, scal, total;
     size_t dis_call;   // bytes of one scorer call workspace
     int rows;  // rows of one chunk
 };
@@ -759,7 +825,13 @@ LeakLayout layout(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, i
     o.cm = take(N * H * sizeof(float));
     o.rg = take(2 * N * K * sizeof(float));   // the goal in force and the one being rebuilt
     o.ring = take(4 * N * K * sizeof(double));
-    o.z = take(N * ((size_t)K * H + K) * sizeof(float));
+    const bool split = g->precision == TG_GEN_SPLIT_F16;
+    const long ldz = (long)K * H + K;
+    o.z = take(split ? 0 : N * (size_t)ldz * sizeof(float));
+    o.wcat = take(split ? (size_t)g->V * ldz * sizeof(float) : 0);
+    o.wfrag = take(split ? tg_fg_bytes(g->V, ldz) : 0);
+    o.zfrag = take(split ? tg_fg_bytes((long)N, ldz) : 0);
+    o.scal = take(split ? 256 : 0);
     o.mpre = take(N * (size_t)4 * H * sizeof(float));
     o.logits = take(N * (size_t)g->V * sizeof(float));
     o.prep = take(((size_t)K * H + K + (size_t)H * H + H + 1 + (size_t)B * K) * sizeof(double));
@@ -790,6 +862,10 @@ int check_leak(const TgLeakWeights* g, const TgDisWeights* d, int B, int L, int 
         g->step_size < 1) {
         tg_set_error("tg_leak_rollout: shape V=%d E=%d H=%d K=%d step=%d not supported (H a multiple of 32 up to %d, "
                      "goal_size <= 64, V <= 65536)", g->V, g->E, g->H, g->K, g->step_size, kMaxHLeak);
+        return TG_ERR_ARG;
+    }
+    if (g->precision != TG_GEN_FP32 && g->precision != TG_GEN_SPLIT_F16) {
+        tg_set_error("tg_leak_rollout: unknown precision %d", g->precision);
         return TG_ERR_ARG;
     }
     if (g->G != d->F) {
@@ -853,6 +929,15 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     a.cm = reinterpret_cast<float*>(ws + lo.cm);
     a.ring = reinterpret_cast<double*>(ws + lo.ring);
     a.z = reinterpret_cast<float*>(ws + lo.z);
+    a.split = g->precision == TG_GEN_SPLIT_F16;
+    a.zfrag = reinterpret_cast<f16x8*>(ws + lo.zfrag);
+    a.zKB = tg_fg_kb((long)g->K * g->H + g->K);
+    {
+        // |z| <= temperature (|rg| <= 1, |h_w| < 1): the power of two that keeps temperature * sZ below 2^15
+        float t = g->temperature > 1.f ? g->temperature : 1.f;
+        a.sZ = 16384.f;
+        while (t > 1.f && a.sZ > 1.f) { t *= 0.5f; a.sZ *= 0.5f; }
+    }
     a.mpre = reinterpret_cast<float*>(ws + lo.mpre);
     a.logits = reinterpret_cast<float*>(ws + lo.logits);
     a.prep = reinterpret_cast<const double*>(ws + lo.prep);
@@ -939,6 +1024,21 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     const int n_prep = K * H + K + H * H + H + 1 + B * K;
     hipLaunchKernelGGL(k_leak_prep, dim3(n_prep), dim3(64), 0, stream, *g, B,
                        reinterpret_cast<double*>(ws + lo.prep));
+    float* pscal = reinterpret_cast<float*>(ws + lo.scal);
+    if (a.split) {
+        // work2goal once per call as the projection GEMM's B pieces: [V, K*H + K] fp32, its |max|, the scales, the pieces
+        const long ldz = (long)K * H + K;
+        float* wcat = reinterpret_cast<float*>(ws + lo.wcat);
+        unsigned* absmax = reinterpret_cast<unsigned*>(pscal + 16);
+        if (hipMemsetAsync(absmax, 0, 16, stream) != hipSuccess) {
+            tg_set_error("hipMemsetAsync failed");
+            return TG_ERR_LAUNCH;
+        }
+        hipLaunchKernelGGL(k_leak_wcat, dim3(2048), dim3(256), 0, stream, *g, wcat);
+        tg_fg_absmax(stream, wcat, (size_t)g->V * ldz, absmax);
+        hipLaunchKernelGGL(k_leak_scales, dim3(1), dim3(64), 0, stream, absmax, a.sZ, pscal);
+        tg_fg_to_frag(stream, wcat, ldz, 1, g->V, ldz, pscal, 0, ws + lo.wfrag);
+    }
     const int ci = chunk_indices(g, B, T, i_hi - i_lo);
     // the manager's output reaches the tokens only through the real goal, rebuilt at pos > 0 with pos % step_size == 0
     // and read by the worker from pos + 1 on; the last worker pass is at L - 2, so the manager's chain ends at the
@@ -990,6 +1090,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
             a.rg_wr = rgbuf[(epoch_at(pos) + 1) & 1];
             a.feat = featbuf[pos % kFeatSets];
         };
+        int proj_rc = TG_OK;
         auto tokens_pass = [&](int pos) {
             at(pos);
             // the worker -- and the rows that join here -- read the goal the manager pass of the position before rebuilt
@@ -1014,7 +1115,13 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
                 tg_prof_end(stream);
             }
             tg_prof_begin(TG_KERNEL_LEAK_PROJ, stream);
-            hipLaunchKernelGGL(k_leak_proj, dim3((g->V + 127) / 128, (a.N + 127) / 128), dim3(256), 0, stream, a);
+            if (a.split) {
+                const int rcp = tg_fg_gemm_rows(stream, a.zfrag, a.N, ws + lo.wfrag, g->V, (long)K * H + K, a.logits, g->V,
+                                                pscal, 2);
+                if (rcp) proj_rc = rcp;
+            } else {
+                hipLaunchKernelGGL(k_leak_proj, dim3((g->V + 127) / 128, (a.N + 127) / 128), dim3(256), 0, stream, a);
+            }
             tg_prof_end(stream);
         };
         auto manager_pass = [&](int pos) -> int {
@@ -1048,6 +1155,7 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
             for (int p = pos; p <= last_update; ++p)
                 if (rebuilds(p)) { seg_end = p; break; }
             for (int p = pos; p <= seg_end; ++p) tokens_pass(p);
+            if (proj_rc) return proj_rc;
             for (int p = pos; p <= seg_end && p <= last_update; ++p)
                 if ((rc = manager_pass(p))) return rc;
             pos = seg_end + 1;

@@ -1224,3 +1224,19 @@ int tg_pgw_backward(const TgGenWeights* w, const int64_t* inp, const int64_t* ta
     tg_prof_end(s);
     return launch_ok("tg_gen_pg_backward (GEMM path)");
 }
+
+// ---- exports of the fragment GEMM (tg_pgw.h)
+int tg_fg_rb(long R) { return fg_rb(R); }
+int tg_fg_kb(long K) { return fg_kb(K); }
+size_t tg_fg_bytes(long R, long K) { return fg_bytes(R, K); }
+void tg_fg_absmax(hipStream_t s, const float* x, size_t n, unsigned* out) {
+    hipLaunchKernelGGL(k_absmax_u, dim3(1024), dim3(256), 0, s, x, n, out);
+}
+void tg_fg_to_frag(hipStream_t s, const float* X, long rs, long cs, long R, long K, const float* scal, int si, void* dst) {
+    to_frag(s, X, rs, cs, R, K, scal, si, fg_rb(R), fg_kb(K), dst);
+}
+int tg_fg_gemm_rows(hipStream_t s, const void* Af, long M, const void* Bf, long N, long K, float* out, long ldo,
+                    const float* scal, int inv_idx) {
+    return fgemm(s, Af, fg_rb(M), Bf, fg_kb(K), out, ldo, (int)M, (int)N, scal, inv_idx, nullptr, false, nullptr, true);
+}
+

@@ -166,11 +166,11 @@ def gen_rollout(gen, sentences, R, uniforms, forced=None, g_lo=1, g_hi=None, i_l
 
 @_on_device
 def leak_rollout(gen, dis, sentences, R, given_nums, uniforms, forced=None, i_lo=0, i_hi=None, out=None,
-                 dis_weights=None, dis_precision=None):
+                 dis_weights=None, dis_precision=None, precision=None):
     """tg_leak_rollout: every rollout_mc_search_leakgan(sentences, dis, given_num) of get_reward_leakgan's loops
     (utils/rollout.py:57-126,172-175).  given_nums: the T given_num values (t*step_size + 1 for get_reward_leakgan);
     uniforms [R,T,L,B]; returns completions [R,T,B,L] int64."""
-    w, keep = _lib.leak_weights(gen)
+    w, keep = _lib.leak_weights(gen, precision)
     dw, dkeep = dis_weights if dis_weights is not None else _lib.dis_weights(dis, dis_precision)
     s, _ = _tokens(sentences, "sentences")
     B, L = s.shape

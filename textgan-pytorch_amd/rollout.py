@@ -229,7 +229,8 @@ class ROLLOUT:
             raise RuntimeError("given_num must be in [1, %d]" % L)
         with torch.no_grad():
             u = uniforms if uniforms is not None else self._rand((1, 1, L, B), sentences.device)
-            comp = ops.leak_rollout(self.gen, dis, sentences, 1, [given_num], u, dis_precision=self.dis_precision)
+            comp = ops.leak_rollout(self.gen, dis, sentences, 1, [given_num], u, dis_precision=self.dis_precision,
+                                    precision=self.gen_precision)
         return comp[0, 0]
 
     def get_reward_leakgan(self, sentences, rollout_num, dis, current_k, uniforms=None, dropout_uniforms=None,
@@ -264,7 +265,8 @@ class ROLLOUT:
                 weights = _lib.dis_weights(dis, self.dis_precision)
                 F = weights[0].F
                 with self._timed("leak_rollout"):
-                    comp = ops.leak_rollout(self.gen, dis, sentences, Rl, given, u, dis_weights=weights)
+                    comp = ops.leak_rollout(self.gen, dis, sentences, Rl, given, u, dis_weights=weights,
+                                            precision=self.gen_precision)
                 p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
                 du, seed = None, None
                 if p > 0 and dropout_uniforms is not None:
