@@ -938,9 +938,11 @@ def test_leak_rollout_and_reward(name, precision):
     assert torch.equal(one, free[0, 1])
 
 
-def test_leak_reward_c1_shape_full_vs_oracle():
+@pytest.mark.parametrize("gen_precision", ["fp32", "split_f16"])
+def test_leak_reward_c1_shape_full_vs_oracle(gen_precision):
     """run_leakgan.py's configuration at full size (V5000 L20 E=H=32 goal 16 step 4, B64, rollout_num 4: 1 280
-    completions, 14 080 draws) against the oracle: step-wise token parity with CDF-tie check, rewards of agreeing rows."""
+    completions, 14 080 draws) against the oracle: step-wise token parity with CDF-tie check, rewards of agreeing rows.
+    gen_precision: the work2goal projection exact in fp32 or as split-fp16 products (TgLeakWeights.precision)."""
     V, E, H, K, L, B, R, step = 5000, 32, 32, 16, 20, 64, 4, 4
     gsd = synth.leak_state(V, E, H, K, 1720, B, seed=7, std=0.2)
     dsd = synth.dis_state(V, 64, *synth.SEQGAN_D_FILTERS, n_out=2, seed=7)
@@ -951,9 +953,11 @@ def test_leak_reward_c1_shape_full_vs_oracle():
     sent, u = synth.tokens(71, (B, L), V), synth.uniform01(72, (R, T, L, B))
     o = oracle.get_reward_leakgan(og, od, sent, R, u)
     given = [t * step + 1 for t in range(T)]
-    replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(o["completions"]))
+    replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(o["completions"]), precision=gen_precision)
     _cases.check_leak_token_parity(replay.cpu().numpy(), o["completions"], u, og, od)
-    rew, raw, comp = tg.ROLLOUT(gen).get_reward_leakgan(_t(sent), R, dis, 0, uniforms=_t(u), return_parts=True)
+    ro = tg.ROLLOUT(gen)
+    ro.gen_precision = gen_precision
+    rew, raw, comp = ro.get_reward_leakgan(_t(sent), R, dis, 0, uniforms=_t(u), return_parts=True)
     same = (comp.cpu().numpy() == o["completions"]).all(-1).reshape(R * T, B)
     assert same.mean() >= 0.97
     np.testing.assert_allclose(raw.cpu().numpy()[same], o["raw"][same], atol=1e-4, rtol=0)
@@ -964,8 +968,9 @@ def test_leak_reward_c1_shape_full_vs_oracle():
         assert torch.equal(comp[:, t, :, :given[t]], _t(sent)[:, :given[t]].expand(R, B, given[t]))
 
 
+@pytest.mark.parametrize("gen_precision", ["fp32", "split_f16"])
 @pytest.mark.parametrize("H", [32, 64])
-def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, monkeypatch):
+def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, gen_precision, monkeypatch):
     """tg_leak_rollout shares the sentence-fed part of every row with one leader row per sentence, orders its rows by
     given_num and spreads the call over four streams.  None of that may show in the tokens: a call with given_nums
     unsorted, repeated and equal to L gives, for each of them, exactly the rows the plain ascending call gives for that
@@ -981,10 +986,10 @@ def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, monkeypatch):
     T = L // step
     given = [t * step + 1 for t in range(T)]
     sent, u = synth.tokens(91, (B, L), V), synth.uniform01(92, (R, T, L, B))
-    std = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u))
+    std = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), precision=gen_precision)
     mixed = [9, 1, L, 9, 17, 5, 13]
     um = np.stack([u[:, given.index(g)] if g in given else u[:, 0] for g in mixed], axis=1)
-    got = tg.ops.leak_rollout(gen, dis, _t(sent), R, mixed, _t(np.ascontiguousarray(um)))
+    got = tg.ops.leak_rollout(gen, dis, _t(sent), R, mixed, _t(np.ascontiguousarray(um)), precision=gen_precision)
     for j, g in enumerate(mixed):
         if g == L:
             assert torch.equal(got[:, j], _t(sent).expand(R, B, L))
@@ -992,17 +997,17 @@ def test_leak_rollout_given_nums_in_any_order_and_stream_modes(H, monkeypatch):
             assert torch.equal(got[:, j], std[:, given.index(g)]), "given_num %d at index %d" % (g, j)
     # a shard of the rollout index: its own leaders, the same rows
     part = torch.full_like(std, -1)
-    tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), i_lo=2, i_hi=3, out=part)
+    tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), i_lo=2, i_hi=3, out=part, precision=gen_precision)
     assert torch.equal(part[2], std[2]) and bool((part[:2] == -1).all())
     monkeypatch.setenv("TG_LEAK_ONE_STREAM", "1")
-    assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u)), std)
+    assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), precision=gen_precision), std)
     monkeypatch.delenv("TG_LEAK_ONE_STREAM")
     # several chunks of the rollout index in one call (TG_LEAK_LOGITS_BYTES: room for one rollout index per chunk)
     monkeypatch.setenv("TG_LEAK_LOGITS_BYTES", str((B + T * B) * V * 4))
-    assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u)), std)
+    assert torch.equal(tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), precision=gen_precision), std)
     monkeypatch.delenv("TG_LEAK_LOGITS_BYTES")
     monkeypatch.setenv("TG_LEAK_SPLIT_CELL", "1")
-    other = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u))
+    other = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), precision=gen_precision)
     assert (other == std).all(-1).float().mean() >= 0.97
     if H > 32:
         assert torch.equal(other, std)   # the switch changes nothing where the cell has its own kernel anyway
@@ -1026,8 +1031,9 @@ def test_leak_reward_edge_shapes_against_oracle(V, E, H, K, L, B, R, step):
     du = synth.uniform01(83, (R * T, B, od.F))
     o = oracle.get_reward_leakgan(og, od, sent, R, u, dropout_p=0.2, dropout_uniforms=du)
     given = [t * step + 1 for t in range(T)]
-    replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(o["completions"]))
-    _cases.check_leak_token_parity(replay.cpu().numpy(), o["completions"], u, og, od)
+    for gp in ("fp32", "split_f16"):   # the work2goal projection in both arithmetic modes (K*H + K off every tile size)
+        replay = tg.ops.leak_rollout(gen, dis, _t(sent), R, given, _t(u), forced=_t(o["completions"]), precision=gp)
+        _cases.check_leak_token_parity(replay.cpu().numpy(), o["completions"], u, og, od)
     rew, raw, comp = tg.ROLLOUT(gen).get_reward_leakgan(_t(sent), R, dis, 0, uniforms=_t(u), dropout_uniforms=_t(du),
                                                         return_parts=True)
     assert tuple(rew.shape) == (B, T)
