@@ -2,28 +2,31 @@
 // pair of get_reward_leakgan (utils/rollout.py:57-126, 172-175) driving LeakGAN_G.forward (models/LeakGAN_G.py:52-102)
 // and the discriminator's get_feature (models/discriminator.py:51-64) -- gfx950 only.
 //
-// All rows (rollout index i, given_num index t, sentence b) advance one position together; per position:
-//   k_leak_draw    token of the position: the sentence's (pos < given_num) or the canonical inverse-CDF draw from the
-//                  previous position's outputs; written to the completions and to the feature extractor's input
+// All rows advance one position together (row_ids: one leader row per sentence until its rows reach their given_num,
+// then the (given_num, rollout index, sentence) rows); per position:
+//   k_leak_draw    token of the position: the sentence's (a leader) or the canonical inverse-CDF draw from the previous
+//                  position's outputs; written to the completions and to the feature extractor's input.  With small
+//                  cells the worker's pass below runs in the same kernel (k_leak_draw<true>).
 //   k_leak_worker  worker LSTM cell (token embedding) and the projection operand z = temperature * [rg (x) h_w | rg]
-//   k_leak_proj    outputs[n, v] = z[n, :] . [work2goal.weight[v*K..v*K+K, :] | work2goal.bias[v*K..]]  (fp32 MFMA)
+//   projection     outputs[n, v] = z[n, :] . [work2goal.weight[v*K..v*K+K, :] | work2goal.bias[v*K..]]: k_leak_proj
+//                  (exact fp32 MFMA) or, TG_GEN_SPLIT_F16, tg_pgw.hip's split-fp16 fragment GEMM on z written as pieces
 // and, beside that chain:
 //   tg_dis_features  the scorer's get_feature over the rows' tokens so far (tg_dis.hip: conv + max-pool + highway on
-//                  the matrix cores, weights prepared once per call and workspace)
+//                  the matrix cores; weights prepared once per call)
 //   k_leak_mgates, k_leak_manager  manager LSTM cell (feature), the goal bookkeeping
 //
 // Streams.  The manager's side reaches the tokens only through the real goal rg, which is rebuilt every step_size
-// positions (utils/rollout.py:89-93); between two rebuilds the tokens' chain draw -> worker -> proj -> draw needs
+// positions (utils/rollout.py:89-93); between two rebuilds the tokens' chain draw -> worker -> projection -> draw needs
 // nothing from it, and the feature passes of different positions need nothing from each other (only the manager's
-// cells are a chain).  At run_leakgan.py's shape every kernel here is a few dozen workgroups -- latency, not
-// throughput -- so the call spreads over four streams: the caller's (tokens' chain), two of the device's own for the
-// feature passes of even and odd positions, one for the manager's cells; events order them (draw(pos) ->
+// cells are a chain).  So the call spreads over four streams: the caller's (tokens' chain), two of the device's own
+// for the feature passes of even and odd positions, one for the manager's cells; events order them (draw(pos) ->
 // feature(pos) -> manager(pos) -> worker(pos + 1) where pos rebuilt the goal).  Feature buffers and scorer call
 // workspaces come in sets of kFeatSets, used round-robin by position (manager(pos - kFeatSets) -> feature(pos) for
-// their reuse); the scorer's prepared weights are shared by all sets and written once per call.  rg is a pair of buffers (the one in force, the one being
-// rebuilt) and the feature pass reads positions > pos as padding by argument, so no stream reads what another is
-// writing.  Manager passes behind the last rebuild that a worker pass still reads are not run.  Results do not depend
-// on the spread: TG_LEAK_ONE_STREAM=1 puts everything on the caller's stream (same bits, for timing comparisons).
+// their reuse); the scorer's prepared weights are shared by all sets and written once per call.  rg is a pair of
+// buffers (the one in force, the one being rebuilt) and the feature pass reads positions > pos as padding by
+// argument, so no stream reads what another is writing.  Manager passes behind the last rebuild that a worker pass
+// still reads are not run.  Results do not depend on the spread: TG_LEAK_ONE_STREAM=1 puts everything on the caller's
+// stream (same bits, for timing comparisons).
 //
 // Goal algebra.  The reference keeps cur_goal = normalize(mana2goal(h_m)) (G = 1720 values per row and position)
 // and uses it only through rg = normalize(goal2goal(real_goal)), real_goal = a sum of four cur_goals (+ goal_init).
@@ -42,7 +45,7 @@
 
 namespace {
 
-constexpr int kLRows = 32;      // rows per workgroup of k_leak_cells
+constexpr int kLRows = 32;      // rows per workgroup of k_leak_worker / k_leak_manager
 constexpr int kLThreads = 256;
 constexpr int kMaxT = 64;       // given_num values per call
 constexpr int kNSpan = 8;       // canonical sampler: spans per row
