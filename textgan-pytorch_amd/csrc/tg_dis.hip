@@ -534,7 +534,18 @@ __device__ __forceinline__ void block_atomic_max(unsigned m, unsigned* out) {
 // workgroup bx of nb: |max| of x[0..n) as ordered bits (NaN sorts high: scale 1 below)
 __device__ __forceinline__ unsigned absmax_part(const float* x, size_t n, int bx, int nb) {
     unsigned m = 0;
-    for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nb * 256)
+    size_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) == 0) {   // 16 bytes per lane and load while the tensor allows it
+        const size_t n4 = n >> 2;
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x);
+        for (size_t i = (size_t)bx * 256 + threadIdx.x; i < n4; i += (size_t)nb * 256) {
+            const f32x4 v = x4[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
+        }
+        done = n4 << 2;
+    }
+    for (size_t i = done + (size_t)bx * 256 + threadIdx.x; i < n; i += (size_t)nb * 256)
         m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
     return m;
 }
