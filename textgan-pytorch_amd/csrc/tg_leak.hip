@@ -1024,6 +1024,10 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
     const size_t ev_draw = 0, ev_feat = (size_t)L, ev_mgr = 2 * (size_t)L;   // one event per position each
     const size_t ev_fork = 3 * (size_t)L, ev_prep = ev_fork + 1;
 
+    // where the side streams may start: behind whatever the caller's stream did with this memory before the call, not
+    // behind this call's own kernels on that stream (they write other parts of the workspace)
+    record(ev_fork, stream);
+    bool forked = true;
     const int n_prep = K * H + K + H * H + H + 1 + B * K;
     hipLaunchKernelGGL(k_leak_prep, dim3(n_prep), dim3(64), 0, stream, *g, B,
                        reinterpret_cast<double*>(ws + lo.prep));
@@ -1068,7 +1072,8 @@ extern "C" int tg_leak_rollout(const TgLeakWeights* g, const TgDisWeights* d, co
         if (last_update >= 0 && prepared_n != a.Nmax) {
             // the scorer's weights, once for all the call workspaces, on the first feature stream -- behind whatever
             // the caller's stream did with this memory before; the other feature stream waits for it once
-            record(ev_fork, stream);
+            if (!forked) record(ev_fork, stream);   // a later chunk of another size: behind the chunks before it
+            forked = false;
             wait(fstream[0], ev_fork);
             rc = tg_dis_features_prepare(d, a.Nmax, L, featbuf[0], call_ws, kFeatSets, lo.dis_call, ws + lo.dis_w, fstream[0]);
             if (rc) return rc;
