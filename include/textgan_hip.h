@@ -244,6 +244,17 @@ int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, int L,
                  int col, float dropout_p, const float* dropout_uniforms,
                  float* reward_out, float* logits_out, float* feature_out,
                  void* workspace, size_t workspace_bytes, void* stream);
+/* tg_dis_score in two calls on the same workspace, same results to the bit (see tg_dis_score_rollout_prepare below):
+ * ..._prepare does what needs only D's parameters, ..._prepared the rest.  get_reward_leakgan (utils/rollout.py:156-184)
+ * scores its completions after the rollouts; the shim enqueues the first part on a second stream beside them.
+ * dropout_uniforms / feature_out: the pointers the second call will pass (their alignment decides which highway
+ * kernel the weights are prepared for), or NULL; nothing is read or written through them here. */
+int tg_dis_score_prepare(const TgDisWeights* w, int N, int L, const float* dropout_uniforms, const float* feature_out,
+                         void* workspace, size_t workspace_bytes, void* stream);
+int tg_dis_score_prepared(const TgDisWeights* w, const int64_t* seqs, int N, int L,
+                          int col, float dropout_p, const float* dropout_uniforms,
+                          float* reward_out, float* logits_out, float* feature_out,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
  * CNN discriminator scorer for rollout completions.

@@ -928,6 +928,14 @@ def test_leak_rollout_and_reward(name, precision):
     rew, raw, comp = ro.get_reward_leakgan(_t(sent), R, dis, int(c["current_k"]), uniforms=_t(u),
                                            dropout_uniforms=None if du is None else _t(du), return_parts=True)
     assert rew.is_cuda and tuple(rew.shape) == (B, T) and torch.equal(comp, free)
+    # the final scoring's preparation runs on a second stream beside the rollout (tg_dis_score_prepare / _prepared):
+    # the same bits as the one-call path
+    ro.overlap_prepare = False
+    rew1, raw1, _ = ro.get_reward_leakgan(_t(sent), R, dis, int(c["current_k"]), uniforms=_t(u),
+                                          dropout_uniforms=None if du is None else _t(du), return_parts=True)
+    ro.overlap_prepare = True
+    if du is not None or not int(c["dropout"]):   # (counter-based masks take a fresh seed per call)
+        assert torch.equal(raw1, raw) and torch.equal(rew1, rew)
     comp, raw, rew = comp.cpu().numpy(), raw.cpu().numpy(), rew.cpu().numpy()
     same = (comp == ref).all(-1).reshape(R * T, B)
     np.testing.assert_allclose(raw[same], c["raw"][same], atol=1e-4, rtol=0)

@@ -20,7 +20,7 @@ SYMBOLS = ["tg_version", "tg_last_error", "tg_gen_supported", "tg_gen_teacher_fo
            "tg_gen_rollout_workspace_bytes", "tg_gen_rollout", "tg_gen_sample_workspace_bytes", "tg_gen_sample",
            "tg_gen_sample_static_bytes", "tg_gen_sample_static",
            "tg_dis_workspace_bytes",
-           "tg_dis_score", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_score_rollout_prepare",
+           "tg_dis_score", "tg_dis_score_prepare", "tg_dis_score_prepared", "tg_dis_score_rollout_workspace_bytes", "tg_dis_score_rollout", "tg_dis_score_rollout_prepare",
            "tg_dis_score_rollout_prepared", "tg_dis_rescore_dropout",
            "tg_gen_nll_workspace_bytes", "tg_gen_nll", "tg_gen_pg_forward", "tg_gen_pg_backward_workspace_bytes", "tg_gen_pg_backward",
            "tg_leak_rollout_workspace_bytes", "tg_leak_rollout",
@@ -94,6 +94,11 @@ def lib():
         l.tg_gen_sample_static.restype = C.c_int
         l.tg_dis_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float] + [C.c_void_p] * 5 + \
                                   [C.c_size_t, C.c_void_p]
+        l.tg_dis_score_prepared.argtypes = l.tg_dis_score.argtypes
+        l.tg_dis_score_prepared.restype = C.c_int
+        l.tg_dis_score_prepare.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t,
+                                           C.c_void_p]
+        l.tg_dis_score_prepare.restype = C.c_int
         l.tg_dis_score_rollout_workspace_bytes.restype = C.c_size_t
         l.tg_dis_score_rollout_workspace_bytes.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
         l.tg_dis_score_rollout.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float] + [C.c_void_p] * 3 + \

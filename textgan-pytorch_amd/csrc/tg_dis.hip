@@ -1933,6 +1933,31 @@ extern "C" int tg_dis_score(const TgDisWeights* w, const int64_t* seqs, int N, i
                       feature_out, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+// tg_dis_score in two parts, like tg_dis_score_rollout: what needs only the weights (|max|, scales, pieces), and the rest
+extern "C" int tg_dis_score_prepare(const TgDisWeights* w, int N, int L, const float* dropout_uniforms,
+                                    const float* feature_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (N == 0 && L >= 1) return TG_OK;
+    if (N < 0 || !workspace) {
+        tg_set_error("tg_dis_score_prepare: bad arguments (N=%d L=%d)", N, L);
+        return TG_ERR_ARG;
+    }
+    FeatOpts fo;
+    fo.mode = FeatOpts::kPrepareOnly;
+    // no sequence is read and nothing is written through the output pointers in this mode: the workspace stands in for
+    // the sequences' pointer check, the caller's pointers only decide (by their alignment) which highway is prepared
+    return score_impl(w, reinterpret_cast<const int64_t*>(workspace), N, L, nullptr, 0, 0, 0.f, dropout_uniforms, nullptr,
+                      nullptr, const_cast<float*>(feature_out), workspace, workspace_bytes, (hipStream_t)stream, fo);
+}
+
+extern "C" int tg_dis_score_prepared(const TgDisWeights* w, const int64_t* seqs, int N, int L, int col, float dropout_p,
+                                     const float* dropout_uniforms, float* reward_out, float* logits_out,
+                                     float* feature_out, void* workspace, size_t workspace_bytes, void* stream) {
+    FeatOpts fo;
+    fo.reuse = true;
+    return score_impl(w, seqs, N, L, nullptr, 0, col, dropout_p, dropout_uniforms, reward_out, logits_out,
+                      feature_out, workspace, workspace_bytes, (hipStream_t)stream, fo);
+}
+
 // get_feature for the LeakGAN rollout's position loop (tg_leak.hip): tg_dis_score restricted to feature_out, reading
 // the tokens at positions >= valid_len as padding (token 0).  The prepared weights live in weights_ws, shared by any
 // number of per-call workspaces (each laid out for N_layout sequences): tg_dis_features_prepare once per (w, N_layout),

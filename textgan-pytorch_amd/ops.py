@@ -221,10 +221,24 @@ def _dropout_args(w, N, dropout_p, dropout_uniforms, dropout_seed, count):
 
 
 @_on_device
+def dis_score_prepare(dis, N, L, device, dropout_uniforms=None, weights=None, precision=None):
+    """tg_dis_score_prepare: the part of the scorer that needs only D's parameters, enqueued on the current stream.
+    Returns the workspace to hand to dis_score(..., prepared=ws) for N sequences of length L (rewards only)."""
+    w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
+    nbytes = _lib.lib().tg_dis_workspace_bytes(C.byref(w), N, L)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=device)
+    du = None if dropout_uniforms is None else _lib.dev_ptr(dropout_uniforms, F32, "dropout_uniforms")
+    _lib.check(_lib.lib().tg_dis_score_prepare(C.byref(w), N, L, du, None, _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))
+    return ws
+
+
+@_on_device
 def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_reward=True, want_logits=False,
-              want_feature=False, reward_out=None, weights=None, precision=None, dropout_seed=None):
+              want_feature=False, reward_out=None, weights=None, precision=None, dropout_seed=None, prepared=None):
     """tg_dis_score: CNNDiscriminator.forward (models/discriminator.py:40-64) + softmax column
-    (utils/rollout.py:146-148).  seqs [N,L]; returns dict(reward [N], logits [N,n_out], feature [N,F])."""
+    (utils/rollout.py:146-148).  seqs [N,L]; returns dict(reward [N], logits [N,n_out], feature [N,F]).
+    prepared: the workspace dis_score_prepare returned for the same D, N and L (no features then: the preparation
+    was made for the pointers of a rewards-only call)."""
     w, keep = weights if weights is not None else _lib.dis_weights(dis, precision)
     s, _ = _tokens(seqs, "seqs")
     N, L = s.shape
@@ -234,8 +248,11 @@ def dis_score(dis, seqs, col=1, dropout_p=0.0, dropout_uniforms=None, want_rewar
     feat = torch.empty(N, w.F, dtype=F32, device=dev) if want_feature else None
     du = _dropout_args(w, N, dropout_p, dropout_uniforms, dropout_seed, N * w.F)
     nbytes = _lib.lib().tg_dis_workspace_bytes(C.byref(w), N, L)
-    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-    _lib.check(_lib.lib().tg_dis_score(
+    if prepared is not None and (prepared.numel() < nbytes or want_feature):
+        raise RuntimeError("textgan_hip: the prepared workspace does not fit this call")
+    ws = prepared if prepared is not None else torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    fn = _lib.lib().tg_dis_score_prepared if prepared is not None else _lib.lib().tg_dis_score
+    _lib.check(fn(
         C.byref(w), _lib.dev_ptr(s, I64, "seqs"), N, L, int(col), float(dropout_p),
         du, _lib.dev_ptr(reward), _lib.dev_ptr(logits),
         _lib.dev_ptr(feat), _lib.dev_ptr(ws), nbytes, _lib.stream_ptr()))

@@ -264,9 +264,6 @@ class ROLLOUT:
             if Rl > 0:
                 weights = _lib.dis_weights(dis, self.dis_precision)
                 F = weights[0].F
-                with self._timed("leak_rollout"):
-                    comp = ops.leak_rollout(self.gen, dis, sentences, Rl, given, u, dis_weights=weights,
-                                            precision=self.gen_precision)
                 p = float(dis.dropout.p) if (dis.training and dis.dropout.p > 0) else 0.0
                 du, seed = None, None
                 if p > 0 and dropout_uniforms is not None:
@@ -275,9 +272,27 @@ class ROLLOUT:
                     du = self._rand((Rl * T * B, F), dev, plan)
                 elif p > 0:
                     seed = _lib.next_dropout_seed(plan.rank)
+                prepared = None
+                if self.overlap_prepare:
+                    # as in get_reward: the final scoring's preparation on a second stream, beside the rollout
+                    cur = torch.cuda.current_stream(dev)
+                    side = self._side.get(dev)
+                    if side is None:
+                        side = self._side[dev] = torch.cuda.Stream(dev)
+                    fork = torch.cuda.Event()
+                    fork.record(cur)
+                with self._timed("leak_rollout"):
+                    comp = ops.leak_rollout(self.gen, dis, sentences, Rl, given, u, dis_weights=weights,
+                                            precision=self.gen_precision)
+                if self.overlap_prepare:
+                    side.wait_event(fork)
+                    with torch.cuda.stream(side):
+                        prepared = ops.dis_score_prepare(dis, Rl * T * B, L, dev, dropout_uniforms=du, weights=weights)
+                    cur.wait_stream(side)
+                    prepared.record_stream(cur)
                 with self._timed("dis_score"):
                     ops.dis_score(dis, comp.view(Rl * T * B, L), col=current_k + 1, dropout_p=p, dropout_uniforms=du,
-                                  reward_out=raw_local.view(-1), weights=weights, dropout_seed=seed)
+                                  reward_out=raw_local.view(-1), weights=weights, dropout_seed=seed, prepared=prepared)
             with self._timed("exchange"):
                 raw = tdist.gather_rows(raw_local, plan, T, self.group)
             with self._timed("reduce"):
